@@ -1,0 +1,171 @@
+/*
+ * kami_hip.h — C ABI of libkamihip.so, the MI355X (gfx950) leaf-evaluation engine.
+ *
+ * This is the drop-in boundary for ONE path of codeandkey/kami: board->plane
+ * encoding (kami/env.h:202-262, Env::observe) and the batched network forward
+ * behind kami::NN::infer (kami/nn/nn.cpp:155-187 -> NNModule::forward nn.cpp:59-91
+ * -> NNResidual::forward nn.cpp:26-34).  Everything is extern "C", plain pointers
+ * and sizes; no torch / C++ types cross this line.  The C++ class kami::NN in
+ * kami_amd/host/nn.h and the ctypes mirror in kami_amd/nn.py sit on top of it.
+ *
+ * Each entry point names the reference interface it replaces (file:line under
+ * the reference tree).
+ */
+#ifndef KAMI_HIP_H
+#define KAMI_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* Constants of the reference model (kami/env.h:19-23, kami/nn/nn.cpp:47-52). */
+#define KH_WIDTH          8
+#define KH_HEIGHT         8
+#define KH_NFEATURES      30      /* env.h:19  NFEATURES = 8+6+4+12            */
+#define KH_POLICY_PLANES  73      /* nn.cpp:51 policyconv2 out channels        */
+#define KH_PSIZE          4672    /* env.h:20  PSIZE = 73*64                   */
+#define KH_POLICY_MID     128     /* nn.cpp:47,50 policyconv out channels      */
+#define KH_VALUE_WIDTH    256     /* nn.cpp:52 valuefc = Linear(w*h, 256)      */
+
+/* Status codes.  kami::NN (host/nn.h) maps 4/5 to the reference's exception
+ * strings "inference policy output contains NaN" / "inference value output
+ * contains NaN" (nn.cpp:176-180). */
+enum {
+    KH_OK = 0,
+    KH_ERR_INVALID = 1,      /* bad argument / unsupported configuration      */
+    KH_ERR_HIP = 2,          /* HIP runtime error (message in kh_last_error)  */
+    KH_ERR_NO_WEIGHTS = 3,   /* infer before kh_load_weights                  */
+    KH_ERR_NAN_POLICY = 4,
+    KH_ERR_NAN_VALUE = 5,
+    KH_ERR_NO_DEVICE = 6     /* no gfx950 device visible: the engine has NO CPU fallback */
+};
+
+/* Arithmetic type of the conv tower (accumulation is always fp32). */
+enum { KH_F32 = 0, KH_BF16 = 1, KH_F16 = 2 };
+
+/* What kh_infer writes to value[0..batch):
+ *  REFERENCE_FLAT: the first `batch` floats of the flattened [batch,256] value
+ *      tensor — bit-for-bit what nn.cpp:186 memcpy's.
+ *  PER_SAMPLE0:    value[i] = vh[i][0]  (opt-in, not reference behaviour). */
+enum { KH_VALUE_REFERENCE_FLAT = 0, KH_VALUE_PER_SAMPLE0 = 1 };
+
+/* Construction parameters: NN::NN(width,height,features,psize) nn.h:50 plus the
+ * two option keys the module reads, "filters"/"residuals" (nn.cpp:42-43). */
+typedef struct kh_config {
+    int32_t width, height;   /* must be 8, 8                                   */
+    int32_t features;        /* input planes F (30 = reference encoder; 119 = BASELINE metric) */
+    int32_t psize;           /* must be 4672                                   */
+    int32_t filters;         /* C                                              */
+    int32_t residuals;       /* R                                              */
+    int32_t dtype;           /* KH_F32 | KH_BF16 | KH_F16                      */
+    int32_t value_mode;      /* KH_VALUE_*                                     */
+    int32_t device;          /* HIP device ordinal                             */
+    int32_t reserved[7];     /* zero                                           */
+} kh_config;
+
+/* Compact board record: exactly the state Env::observe reads (env.h:202-262):
+ * piece placement (board.h:14 piece_occ/color_occ), side to move (position.h:40),
+ * top-of-stack castle_rights and halfmove_clock (position.h:27,30) and
+ * history.size() (env.h:211).  80 bytes, 16-byte aligned loads on device. */
+typedef struct kh_board {
+    uint64_t piece_occ[6];   /* P,N,B,R,Q,K (types.h:44-49), bit = square rank*8+file */
+    uint64_t color_occ[2];   /* white, black                                   */
+    int32_t  ply;            /* history.size()                                 */
+    int32_t  halfmove_clock;
+    uint8_t  ctm;            /* 0 white, 1 black                               */
+    uint8_t  castle_rights;  /* WK=1 WQ=2 BK=4 BQ=8 (position.h:13-16)         */
+    uint8_t  pad[6];
+} kh_board;
+
+typedef struct kh_engine kh_engine;
+
+/* Number of fp32 values in a weight blob for (features, filters, residuals).
+ * Blob order (all fp32, row-major, libtorch shapes; names per nn.cpp:20-23,45-56):
+ *   conv1.weight[C,F,3,3] conv1.bias[C] batchnorm1.{weight,bias,running_mean,running_var}[C]
+ *   for i in 0..R-1: residual{i}.conv1.weight[C,C,3,3] .conv1.bias[C]
+ *                    residual{i}.batchnorm1.{weight,bias,running_mean,running_var}[C]
+ *                    residual{i}.conv2.weight[C,C,3,3] .conv2.bias[C]
+ *                    residual{i}.batchnorm2.{weight,bias,running_mean,running_var}[C]
+ *   policyconv.weight[128,C,1,1] policyconv.bias[128] pbatchnorm.{w,b,rm,rv}[128]
+ *   policyconv2.weight[73,128,1,1] policyconv2.bias[73]
+ *   valueconv.weight[1,C,1,1] valueconv.bias[1] vbatchnorm.{w,b,rm,rv}[1]
+ *   valuefc.weight[256,64] valuefc.bias[256]                                       */
+size_t kh_weight_count(int features, int filters, int residuals);
+
+/* Replaces NN::NN(...) nn.cpp:107-128.  Fails with KH_ERR_NO_DEVICE when no
+ * gfx950 GPU is visible (there is deliberately no CPU path). */
+int  kh_create(const kh_config* cfg, kh_engine** out);
+void kh_destroy(kh_engine* e);
+
+/* Replaces NN::read's effect on the model (nn.cpp:204-222): install a full
+ * parameter set + generation.  In-flight kh_infer calls finish on the old set. */
+int  kh_load_weights(kh_engine* e, const float* blob, size_t nfloats, int generation);
+
+/* NN::get_generation nn.h:53-59. */
+int  kh_generation(kh_engine* e);
+
+/* NN(NN* other) nn.cpp:130-153: a new engine with the same config and weights. */
+int  kh_clone(kh_engine* src, kh_engine** out);
+
+/* NN::infer nn.cpp:155-187.  Host buffers, caller-owned:
+ *   input  [batch][8][8][F] fp32 channels-last (nn.cpp:157)
+ *   policy [batch][4672]   softmax over all 4672 entries (nn.cpp:78-80)
+ *   value  [batch]         per cfg.value_mode
+ * Returns KH_ERR_NAN_POLICY / KH_ERR_NAN_VALUE where the reference throws. */
+int  kh_infer(kh_engine* e, const float* input, int batch, float* policy, float* value);
+
+/* Diagnostic superset of kh_infer used by the parity tests: additionally returns
+ * the whole value tensor [batch][256] (nn.cpp:86-88) and, if non-NULL, the
+ * pre-softmax policy logits [batch][4672] (nn.cpp:75-79). */
+int  kh_infer_full(kh_engine* e, const float* input, int batch,
+                   float* policy, float* value_full, float* logits);
+
+/* Env::observe env.h:202-262 for a batch of compact records -> fp32 planes
+ * [batch][8][8][30], bit-exact.  Host buffers. */
+int  kh_encode(kh_engine* e, const kh_board* boards, int batch, float* planes);
+
+/* Compact ingest: Env::observe + NN::infer fused on device (selfplay.cpp:133,196
+ * collapsed into one call).  Requires cfg.features == 30. */
+int  kh_encode_infer(kh_engine* e, const kh_board* boards, int batch,
+                     float* policy, float* value);
+
+/* Device-resident variants (pointers are HIP device pointers, `stream` is a
+ * hipStream_t or NULL for the engine's own stream).  Asynchronous: no host sync,
+ * no NaN check.  d_value_full is [batch][256]. */
+int  kh_infer_device(kh_engine* e, const void* d_input, int batch,
+                     float* d_policy, float* d_value_full, void* stream);
+int  kh_encode_device(kh_engine* e, const kh_board* d_boards, int batch,
+                      float* d_planes, void* stream);
+
+/* Timing helper for bench/roofline: runs `iters` back-to-back kh_infer_device
+ * launches on the engine stream bracketed by HIP events recorded on THAT stream
+ * and returns the average milliseconds per launch in *ms_per_launch. */
+int  kh_time_infer_device(kh_engine* e, const void* d_input, int batch,
+                          float* d_policy, float* d_value_full,
+                          int iters, float* ms_per_launch);
+int  kh_time_encode_device(kh_engine* e, const kh_board* d_boards, int batch,
+                           float* d_planes, int iters, float* ms_per_launch);
+
+/* Plain device-memory plumbing so hosts without torch can drive the device API. */
+int  kh_dev_alloc(kh_engine* e, size_t bytes, void** d_ptr);
+int  kh_dev_free(kh_engine* e, void* d_ptr);
+int  kh_memcpy_h2d(kh_engine* e, void* d_dst, const void* h_src, size_t bytes);
+int  kh_memcpy_d2h(kh_engine* e, void* h_dst, const void* d_src, size_t bytes);
+int  kh_sync(kh_engine* e);
+
+/* Number of visible HIP devices (0 when none / no driver). */
+int  kh_device_count(void);
+
+/* Thread-local message for the last non-OK status returned on this thread. */
+const char* kh_last_error(void);
+
+/* Library version string, e.g. "kamihip 0.1 gfx950". */
+const char* kh_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* KAMI_HIP_H */

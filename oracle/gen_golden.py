@@ -1,0 +1,106 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/*.npz from the UNMODIFIED reference (oracle/_ref/kami_ref).
+
+Run in the build container only (needs /root/reference to have built oracle/_ref):
+    make -C oracle && python oracle/gen_golden.py
+The fixtures hold data only: seeds/weights/inputs we generate and the outputs the reference
+computed for them (NN::infer nn.cpp:155-187, NNModule::forward nn.cpp:59-91,
+Env::observe env.h:202-262, Env::actions env.h:398-423).
+"""
+import os
+import subprocess
+import sys
+import tempfile
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from kami_amd import weights as W  # noqa: E402
+
+REF = os.path.join(ROOT, "oracle", "_ref", "kami_ref")
+OUT = os.path.join(ROOT, "tests", "golden")
+
+# name, F, C, R, B, seed, peaky, input kind
+NETS = [
+    ("net_f30_c8_r1", 30, 8, 1, 3, 11, 1.0, "uniform"),
+    ("net_f30_c16_r2_peaky", 30, 16, 2, 4, 12, 30.0, "uniform"),
+    ("net_f30_c64_r2", 30, 64, 2, 2, 13, 1.0, "uniform"),
+    ("net_f119_c32_r1_peaky", 119, 32, 1, 2, 14, 30.0, "uniform"),
+    ("net_f30_c64_r1_planes", 30, 64, 1, 5, 15, 30.0, "planes"),
+    # B > 256 exercises the second row of the Q10 value copy-out (nn.cpp:186)
+    ("net_f30_c8_r0_b300", 30, 8, 0, 300, 16, 30.0, "u8"),
+]
+
+
+def run_infer(tmp, blob, F, C, R, gen, x):
+    wpath = os.path.join(tmp, "w.bin")
+    W.save(wpath, blob, F, C, R, gen)
+    x.astype("<f4").tofile(os.path.join(tmp, "x.f32"))
+    outs = [os.path.join(tmp, n) for n in ("p.f32", "v.f32", "vf.f32")]
+    subprocess.check_call([REF, "infer", wpath, os.path.join(tmp, "x.f32"), str(x.shape[0])] + outs)
+    B = x.shape[0]
+    p = np.fromfile(outs[0], "<f4").reshape(B, W.PSIZE)
+    v = np.fromfile(outs[1], "<f4").reshape(B)
+    vf = np.fromfile(outs[2], "<f4").reshape(B, W.VALUE_WIDTH)
+    return p, v, vf
+
+
+def gen_observe(tmp):
+    path = os.path.join(tmp, "obs.bin")
+    # 6 random games, up to 330 plies each (continues past draw conditions -> ply > 255)
+    subprocess.check_call([REF, "observe", "20240607", "6", "330", path])
+    rec = np.dtype([("ply", "<i4"), ("nact", "<i4"), ("fen", "S104"),
+                    ("actions", "<i4", (128,)), ("obs", "<f4", (1920,))])
+    r = np.fromfile(path, rec)
+    obs = r["obs"]
+    assert np.all(np.isin(obs, [0, 1, 2, 4, 8])), "observe() produced a value outside {0,1,2,4,8}"
+    # thin out: keep every position of game 1 plus every 3rd of the rest, plus all with ply > 250
+    keep = np.zeros(len(r), bool)
+    first_game_end = int(np.argmax(r["ply"][1:] == 0)) + 1
+    keep[:first_game_end] = True
+    keep[::3] = True
+    keep[r["ply"] > 250] = True
+    r = r[keep]
+    nmax = int(r["nact"].max())
+    np.savez_compressed(os.path.join(OUT, "observe_playouts.npz"),
+                        ply=r["ply"], fen=r["fen"], nact=r["nact"],
+                        actions=r["actions"][:, :nmax].astype(np.int16),
+                        obs=r["obs"].astype(np.uint8))
+    print("observe fixtures:", len(r), "positions; max ply", r["ply"].max(),
+          "black-to-move", int((r["ply"] % 2 == 1).sum()))
+    return r
+
+
+def main():
+    os.makedirs(OUT, exist_ok=True)
+    if not os.path.exists(REF):
+        sys.exit("oracle/_ref/kami_ref missing: run `make -C oracle` where /root/reference exists")
+    with tempfile.TemporaryDirectory() as tmp:
+        recs = gen_observe(tmp)
+        planes = recs["obs"].reshape(-1, 8, 8, 30)
+        for name, F, C, R, B, seed, peaky, kind in NETS:
+            blob = W.random_weights(F, C, R, seed=seed, peaky=peaky)
+            rng = np.random.default_rng(seed + 1000)
+            if kind == "uniform":
+                x = rng.random((B, 8, 8, F), dtype=np.float32)
+            elif kind == "u8":  # k/256 grid: exact in fp32, stored as uint8 (x_u8) to keep the file small
+                x = (rng.integers(0, 256, (B, 8, 8, F)).astype(np.float32) / 256.0)
+            else:  # real encoder planes (values 0/1/2/4/8), as the reference feeds its net
+                idx = rng.choice(len(planes), B, replace=False)
+                x = planes[idx].astype(np.float32)
+            gen = 7
+            p, v, vf = run_infer(tmp, blob, F, C, R, gen, x)
+            assert np.allclose(p.sum(1), 1.0, atol=1e-4)
+            # big batches: keep the policy rows around the 256-row seam only (file size)
+            rows = np.arange(B) if B <= 16 else np.array([0, 1, 255, 256, 257, B - 1])
+            np.savez_compressed(os.path.join(OUT, name + ".npz"),
+                                features=F, filters=C, residuals=R, generation=gen,
+                                seed=seed, peaky=peaky, blob=blob,
+                                **({"x_u8": (x * 256).astype(np.uint8)} if kind == "u8" else {"x": x}),
+                                policy_rows=rows, policy=p[rows], value=v, value_full=vf)
+            print(name, "policy range", p.min(), p.max(), "value[0..2]", v[:3])
+
+
+if __name__ == "__main__":
+    main()

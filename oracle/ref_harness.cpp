@@ -1,0 +1,222 @@
+// ref_harness.cpp — drives the UNMODIFIED reference (sources compiled where they lie under
+// /root/reference; recipe: oracle/Makefile) to produce golden vectors and CPU timings.
+// TEST INFRASTRUCTURE.  Output binary goes to oracle/_ref/kami_ref only.
+//
+// Nothing of the reference is copied here: this file only CALLS its public API
+//   kami::NNModule / kami::NN   (kami/nn/nn.h:23-73)
+//   kami::Env                   (kami/env.h:41-485)
+//   kami::options::setInt       (kami/options.h:10)
+//
+// Sub-commands
+//   infer   <weights.bin> <input.f32> <B> <policy.f32> <value_flat.f32> <value_full.f32>
+//   observe <seed> <ngames> <maxply> <out.bin>
+//   bench   <F> <C> <R> <B> <iters> <threads>
+#include "kami/nn/nn.h"
+#include "kami/env.h"
+#include "kami/options.h"
+
+#include <torch/torch.h>
+
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
+#include <fstream>
+#include <random>
+#include <string>
+#include <vector>
+
+using namespace kami;
+
+static std::vector<char> slurp(const char* path)
+{
+    std::ifstream f(path, std::ios::binary);
+    if (!f) { fprintf(stderr, "cannot open %s\n", path); exit(2); }
+    return std::vector<char>((std::istreambuf_iterator<char>(f)), std::istreambuf_iterator<char>());
+}
+
+static void dump(const char* path, const void* p, size_t bytes)
+{
+    FILE* f = fopen(path, "wb");
+    if (!f || fwrite(p, 1, bytes, f) != bytes) { fprintf(stderr, "cannot write %s\n", path); exit(2); }
+    fclose(f);
+}
+
+// Canonical blob order documented in include/kami_hip.h (kh_weight_count).
+static std::vector<std::string> canonical_names(int R)
+{
+    std::vector<std::string> n;
+    auto convbn = [&](const std::string& conv, const std::string& bn) {
+        n.push_back(conv + ".weight"); n.push_back(conv + ".bias");
+        n.push_back(bn + ".weight"); n.push_back(bn + ".bias");
+        n.push_back(bn + ".running_mean"); n.push_back(bn + ".running_var");
+    };
+    convbn("conv1", "batchnorm1");
+    for (int i = 0; i < R; ++i) {
+        std::string r = "residual" + std::to_string(i);
+        convbn(r + ".conv1", r + ".batchnorm1");
+        convbn(r + ".conv2", r + ".batchnorm2");
+    }
+    convbn("policyconv", "pbatchnorm");
+    n.push_back("policyconv2.weight"); n.push_back("policyconv2.bias");
+    convbn("valueconv", "vbatchnorm");
+    n.push_back("valuefc.weight"); n.push_back("valuefc.bias");
+    return n;
+}
+
+struct Blob { int F, C, R, gen; const float* data; size_t n; std::vector<char> raw; };
+
+static Blob read_blob(const char* path)
+{
+    Blob b;
+    b.raw = slurp(path);
+    const int32_t* h = (const int32_t*)b.raw.data();
+    if (b.raw.size() < 32 || h[0] != 0x574d414b /* "KAMW" */) { fprintf(stderr, "bad weight blob\n"); exit(2); }
+    b.F = h[1]; b.C = h[2]; b.R = h[3]; b.gen = h[4];
+    b.data = (const float*)(b.raw.data() + 32);
+    b.n = (b.raw.size() - 32) / 4;
+    return b;
+}
+
+static void fill_module(NNModule& mod, const Blob& b)
+{
+    torch::NoGradGuard g;
+    auto params = mod.named_parameters(true);
+    auto bufs = mod.named_buffers(true);
+    const float* p = b.data;
+    size_t used = 0;
+    for (auto& name : canonical_names(b.R)) {
+        torch::Tensor t;
+        if (params.contains(name)) t = params[name];
+        else if (bufs.contains(name)) t = bufs[name];
+        else { fprintf(stderr, "reference module has no tensor %s\n", name.c_str()); exit(2); }
+        size_t n = t.numel();
+        if (used + n > b.n) { fprintf(stderr, "blob too short at %s\n", name.c_str()); exit(2); }
+        t.copy_(torch::from_blob((void*)p, t.sizes(), torch::kFloat32));
+        p += n; used += n;
+    }
+    if (used != b.n) { fprintf(stderr, "blob has %zu floats, module consumed %zu\n", b.n, used); exit(2); }
+}
+
+static int cmd_infer(int argc, char** argv)
+{
+    if (argc < 8) return 1;
+    Blob b = read_blob(argv[2]);
+    int B = atoi(argv[4]);
+    options::setInt("filters", b.C);
+    options::setInt("residuals", b.R);
+
+    // A module of the reference's own class, filled with the blob, saved the way NN::write
+    // does (nn.cpp:189-202), then ingested by the reference's NN::read (nn.cpp:204-222).
+    auto mod = std::make_shared<NNModule>(8, 8, b.F, PSIZE);
+    fill_module(*mod, b);
+    mod->eval();
+    std::string tmp = std::string(argv[5]) + ".model.pt";
+    {
+        torch::serialize::OutputArchive a;
+        mod->save(a);
+        a.write("generation", torch::IValue(b.gen));
+        a.save_to(tmp);
+    }
+    NN net(8, 8, b.F, PSIZE, /*force_cpu=*/true);
+    net.read(tmp);
+    remove(tmp.c_str());
+    if (net.get_generation() != b.gen) { fprintf(stderr, "generation mismatch\n"); return 2; }
+
+    std::vector<char> in = slurp(argv[3]);
+    if (in.size() != (size_t)B * 64 * b.F * 4) { fprintf(stderr, "input size mismatch\n"); return 2; }
+    std::vector<float> policy((size_t)B * PSIZE), value(B);
+    net.infer((float*)in.data(), B, policy.data(), value.data());          // nn.cpp:155-187
+    dump(argv[5], policy.data(), policy.size() * 4);
+    dump(argv[6], value.data(), value.size() * 4);
+
+    // Whole [B,256] value tensor straight from NNModule::forward (nn.cpp:59-91).
+    {
+        torch::NoGradGuard g;
+        auto x = torch::from_blob(in.data(), { B, 8, 8, b.F }, torch::kFloat32);
+        auto out = mod->forward(x);
+        auto vh = out[1].contiguous();
+        auto ph = out[0].contiguous();
+        if (vh.numel() != (int64_t)B * 256) { fprintf(stderr, "unexpected value shape\n"); return 2; }
+        dump(argv[7], vh.data_ptr<float>(), (size_t)vh.numel() * 4);
+        // NN::infer must agree bit-for-bit with the module it read from disk (test/nndisk.cpp:24-29)
+        if (memcmp(ph.data_ptr<float>(), policy.data(), policy.size() * 4) != 0) {
+            fprintf(stderr, "NN::infer and NNModule::forward disagree\n"); return 2;
+        }
+    }
+    return 0;
+}
+
+// observe record, little-endian:
+//   int32 ply; int32 nact; char fen[104]; int32 actions[128]; float obs[1920]
+static int cmd_observe(int argc, char** argv)
+{
+    if (argc < 6) return 1;
+    unsigned seed = (unsigned)atoi(argv[2]);
+    int ngames = atoi(argv[3]), maxply = atoi(argv[4]);
+    FILE* f = fopen(argv[5], "wb");
+    if (!f) return 2;
+    std::mt19937 rng(seed);
+    long nrec = 0;
+    for (int g = 0; g < ngames; ++g) {
+        Env e;
+        for (int ply = 0; ply <= maxply; ++ply) {
+            std::vector<int> acts = e.actions();                 // env.h:398-423
+            int32_t hdr[2] = { e.ply(), (int32_t)acts.size() };
+            char fen[104] = { 0 };
+            std::string s = e.print();                           // env.h:425-430
+            strncpy(fen, s.c_str(), sizeof(fen) - 1);
+            int32_t a[128] = { 0 };
+            for (size_t i = 0; i < acts.size() && i < 128; ++i) a[i] = acts[i];
+            std::vector<float> obs(OBSIZE);
+            e.observe(obs.data());                               // env.h:202-262
+            fwrite(hdr, 4, 2, f); fwrite(fen, 1, 104, f); fwrite(a, 4, 128, f);
+            fwrite(obs.data(), 4, OBSIZE, f);
+            ++nrec;
+            // keep playing past draw conditions (50-move / repetition) while a legal move
+            // exists, so that ply > 255 and large half-move clocks are covered
+            if (acts.empty()) break;
+            e.push(acts[rng() % acts.size()]);                   // env.h:264-271
+        }
+    }
+    fclose(f);
+    printf("%ld records\n", nrec);
+    return 0;
+}
+
+static int cmd_bench(int argc, char** argv)
+{
+    if (argc < 8) return 1;
+    int F = atoi(argv[2]), C = atoi(argv[3]), R = atoi(argv[4]), B = atoi(argv[5]);
+    int iters = atoi(argv[6]), threads = atoi(argv[7]);
+    options::setInt("filters", C);
+    options::setInt("residuals", R);
+    if (threads > 0) { torch::set_num_threads(threads); }
+    NN net(8, 8, F, PSIZE, true);
+    std::mt19937 rng(20240607);
+    std::uniform_real_distribution<float> u(0.f, 1.f);
+    std::vector<float> in((size_t)B * 64 * F), policy((size_t)B * PSIZE), value(B);
+    for (auto& v : in) v = u(rng);
+    net.infer(in.data(), B, policy.data(), value.data());       // warm-up
+    auto t0 = std::chrono::steady_clock::now();
+    for (int i = 0; i < iters; ++i) net.infer(in.data(), B, policy.data(), value.data());
+    double s = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    printf("{\"evals_per_s\": %.3f, \"seconds\": %.6f, \"iters\": %d, \"batch\": %d, \"threads\": %d, "
+           "\"features\": %d, \"filters\": %d, \"residuals\": %d}\n",
+           (double)iters * B / s, s, iters, B, torch::get_num_threads(), F, C, R);
+    return 0;
+}
+
+int main(int argc, char** argv)
+{
+    if (argc < 2) { fprintf(stderr, "usage: kami_ref infer|observe|bench ...\n"); return 1; }
+    std::string c = argv[1];
+    try {
+        if (c == "infer") return cmd_infer(argc, argv);
+        if (c == "observe") return cmd_observe(argc, argv);
+        if (c == "bench") return cmd_bench(argc, argv);
+    } catch (std::exception& e) {
+        fprintf(stderr, "kami_ref: %s\n", e.what());
+        return 3;
+    }
+    return 1;
+}

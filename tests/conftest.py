@@ -1,0 +1,40 @@
+import glob
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+def load_net_fixture(path):
+    z = np.load(path, allow_pickle=False)
+    d = {k: z[k] for k in z.files}
+    if "x_u8" in d:
+        d["x"] = d.pop("x_u8").astype(np.float32) / 256.0
+    for k in ("features", "filters", "residuals", "generation"):
+        d[k] = int(d[k])
+    d["name"] = os.path.basename(path)[:-4]
+    return d
+
+
+NET_FIXTURES = sorted(glob.glob(os.path.join(GOLDEN, "net_*.npz")))
+
+
+@pytest.fixture(params=NET_FIXTURES, ids=[os.path.basename(p)[:-4] for p in NET_FIXTURES])
+def net_fixture(request):
+    return load_net_fixture(request.param)
+
+
+@pytest.fixture(scope="session")
+def observe_fixture():
+    z = np.load(os.path.join(GOLDEN, "observe_playouts.npz"), allow_pickle=False)
+    return {k: z[k] for k in z.files}
