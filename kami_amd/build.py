@@ -1,0 +1,81 @@
+"""In-tree build of libkamihip.so (HIP kernels + C ABI) for gfx950.
+
+    python -m kami_amd.build            # or kami_amd.build.build_all()
+
+hipcc cross-compiles without a GPU.  Each .hip translation unit is compiled to an object
+with hipcc and the objects are linked with the host C++ driver against ONE HIP runtime:
+the libamdhip64.so that ships inside the torch wheel of this image, when torch is present,
+so that a process which also imports torch (bench.py uses torch.distributed) never ends up
+with two HIP runtimes; /opt/rocm/lib otherwise.
+"""
+from __future__ import annotations
+
+import os
+import shutil
+import subprocess
+import sys
+from concurrent.futures import ThreadPoolExecutor
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+OBJ = os.path.join(CSRC, "build")
+LIB = os.path.join(HERE, "libkamihip.so")
+ARCH = "gfx950"
+SOURCES = ["kh_api.hip", "encode.hip", "forward_simple.hip"]
+HIPCC_FLAGS = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-Wall", "-Wno-unused-result",
+               "-ffp-contract=fast"]
+
+
+def _hip_runtime_dir() -> str:
+    if os.environ.get("KAMI_HIP_LIBDIR"):
+        return os.environ["KAMI_HIP_LIBDIR"]
+    try:
+        import importlib.util
+        spec = importlib.util.find_spec("torch")
+        if spec and spec.origin:
+            d = os.path.join(os.path.dirname(spec.origin), "lib")
+            if os.path.exists(os.path.join(d, "libamdhip64.so")):
+                return d
+    except Exception:
+        pass
+    return "/opt/rocm/lib"
+
+
+def _stale(target: str, deps) -> bool:
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def build_all(force: bool = False, verbose: bool = False) -> str:
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    os.makedirs(OBJ, exist_ok=True)
+    headers = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")]
+    headers.append(os.path.join(os.path.dirname(HERE), "include", "kami_hip.h"))
+    headers.append(os.path.abspath(__file__))
+    jobs = []
+    objs = []
+    for src in SOURCES:
+        s = os.path.join(CSRC, src)
+        o = os.path.join(OBJ, src.replace(".hip", ".o"))
+        objs.append(o)
+        if force or _stale(o, [s] + headers):
+            jobs.append([hipcc] + HIPCC_FLAGS + ["-c", s, "-o", o])
+
+    def run(cmd):
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        subprocess.check_call(cmd)
+
+    with ThreadPoolExecutor(max_workers=min(4, max(1, len(jobs)))) as ex:
+        list(ex.map(run, jobs))
+    if force or jobs or _stale(LIB, objs):
+        rt = _hip_runtime_dir()
+        run(["g++", "-shared", "-o", LIB] + objs +
+            [f"-L{rt}", "-lamdhip64", f"-Wl,-rpath,{rt}", "-lpthread"])
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build_all(force="--force" in sys.argv, verbose=True))

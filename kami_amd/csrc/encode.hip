@@ -1,0 +1,84 @@
+// encode.hip — board -> plane encoding on gfx950.
+//
+// Replaces Env::observe (kami/env.h:202-262) for a batch of compact records (kh_board).
+// Pure integer work, bit-exact; HBM-write bound (7 680 B written per position, 80 B read).
+//
+// One wavefront (64 lanes) per position, lane = POV square:
+//   phase 1  every lane builds its square's 30 channel values in registers and writes them
+//            to the wave's LDS tile [64][30] with 8-byte stores;
+//   phase 2  the tile is streamed to HBM as 480 fully coalesced 16-byte stores.
+// The record itself is wave-uniform and is fetched with scalar loads.
+#include "kh_internal.h"
+
+namespace kh {
+
+constexpr int ENC_WAVES = 4;                 // waves per workgroup
+constexpr int ENC_TILE = 64 * KH_NFEATURES;  // floats per position
+
+__global__ __launch_bounds__(64 * ENC_WAVES) void encode_f32_kernel(const kh_board* __restrict__ boards,
+                                                                    int n, float* __restrict__ planes)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    float* tile = reinterpret_cast<float*>(smem) + wave * ENC_TILE;
+    const int stride = gridDim.x * ENC_WAVES;
+
+    for (int base = blockIdx.x * ENC_WAVES; base < n; base += stride) {
+        const int b = base + wave;            // wave-uniform
+        if (b < n) {
+            const kh_board* r = boards + b;
+            const int ply = r->ply, hmc = r->halfmove_clock;
+            const int ctm = r->ctm & 1, castle = r->castle_rights;
+            // real square seen at POV square `lane` (env.h:246: povsq = 63 - sq for black)
+            const int sq = ctm ? 63 - lane : lane;
+            // piece plane index 0..11 relative to channel 18, or -1 for an empty square
+            int idx = -1;
+#pragma unroll
+            for (int t = 0; t < 6; ++t)
+                if ((r->piece_occ[t] >> sq) & 1) idx = t;
+            const int is_w = (int)((r->color_occ[0] >> sq) & 1);
+            const int is_b = (int)((r->color_occ[1] >> sq) & 1);
+            if (!(is_w | is_b)) idx = -1;
+            // ncPieceColor(pc) != our_col -> +6 (env.h:255-256)
+            if (idx >= 0 && (is_b != ctm)) idx += 6;
+
+            float v[KH_NFEATURES];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) v[i] = (float)((ply >> i) & 1);                 // env.h:213-214
+#pragma unroll
+            for (int i = 0; i < 6; ++i) v[8 + i] = (float)((hmc >> i) & 1);             // env.h:216-218
+            // raw masked castle bits; black swaps the white/black pairs (env.h:220-236)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) v[14 + i] = (float)(castle & (1 << (i ^ (ctm << 1))));
+#pragma unroll
+            for (int i = 0; i < 12; ++i) v[18 + i] = (idx == i) ? 1.0f : 0.0f;         // env.h:258
+
+            float2* dst = reinterpret_cast<float2*>(tile + lane * KH_NFEATURES);         // 120 B rows: 8-B aligned
+#pragma unroll
+            for (int i = 0; i < KH_NFEATURES / 2; ++i) dst[i] = make_float2(v[2 * i], v[2 * i + 1]);
+        }
+        __syncthreads();
+        if (b < n) {
+            const float4* src = reinterpret_cast<const float4*>(tile);
+            float4* out = reinterpret_cast<float4*>(planes + (size_t)b * ENC_TILE);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int q = lane + 64 * j;
+                if (q < ENC_TILE / 4) out[q] = src[q];
+            }
+        }
+        __syncthreads();
+    }
+}
+
+void launch_encode_f32(const kh_board* d_boards, int n, float* d_planes, hipStream_t s)
+{
+    if (n <= 0) return;
+    int wgs = (n + ENC_WAVES - 1) / ENC_WAVES;
+    if (wgs > 256 * 5) wgs = 256 * 5;        // 30 KB LDS per workgroup -> 5 resident per CU
+    hipLaunchKernelGGL(encode_f32_kernel, dim3(wgs), dim3(64 * ENC_WAVES),
+                       ENC_WAVES * ENC_TILE * sizeof(float), s, d_boards, n, d_planes);
+}
+
+}  // namespace kh

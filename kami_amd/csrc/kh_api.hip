@@ -1,0 +1,614 @@
+// kh_api.hip — the C ABI of libkamihip.so (include/kami_hip.h): engine object, weight
+// preparation / hot swap, workspace slots, host-buffer and device-buffer entry points.
+//
+// Boundary being replaced: class kami::NN (kami/nn/nn.h:40-73, kami/nn/nn.cpp:107-222) and
+// Env::observe (kami/env.h:202-262).  There is no CPU fallback anywhere in this library:
+// without a gfx950 device kh_create fails with KH_ERR_NO_DEVICE.
+#include "kh_internal.h"
+
+#include <atomic>
+#include <cmath>
+#include <condition_variable>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <memory>
+#include <mutex>
+#include <string>
+#include <vector>
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(int code, const char* fmt, ...)
+{
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    g_err = buf;
+    return code;
+}
+
+#define HIPCHK(expr)                                                                         \
+    do {                                                                                     \
+        hipError_t _e = (expr);                                                              \
+        if (_e != hipSuccess)                                                                \
+            return fail(KH_ERR_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e),   \
+                        __FILE__, __LINE__);                                                 \
+    } while (0)
+
+struct DevMem {
+    void* p = nullptr;
+    size_t bytes = 0;
+    ~DevMem() { if (p) (void)hipFree(p); }
+    int ensure(size_t n)
+    {
+        if (n <= bytes) return KH_OK;
+        if (p) { (void)hipFree(p); p = nullptr; bytes = 0; }
+        HIPCHK(hipMalloc(&p, n));
+        bytes = n;
+        return KH_OK;
+    }
+    template <class T> T* as() const { return static_cast<T*>(p); }
+};
+
+// ------------------------------------------------------------------------------- weights
+// Host view of the canonical blob (order documented at kh_weight_count in kami_hip.h).
+struct ConvBN { const float *w, *b, *g, *be, *rm, *rv; };
+struct HostNet {
+    ConvBN stem;
+    std::vector<ConvBN> res;
+    ConvBN pconv;
+    const float *p2w, *p2b;
+    ConvBN vconv;
+    const float *fcw, *fcb;
+};
+
+const float* take(const float*& p, size_t n) { const float* r = p; p += n; return r; }
+void take_convbn(const float*& p, ConvBN& c, size_t wn, int co)
+{
+    c.w = take(p, wn); c.b = take(p, co);
+    c.g = take(p, co); c.be = take(p, co); c.rm = take(p, co); c.rv = take(p, co);
+}
+
+HostNet parse_blob(const float* blob, int F, int C, int R)
+{
+    HostNet n;
+    const float* p = blob;
+    take_convbn(p, n.stem, (size_t)C * F * 9, C);
+    n.res.resize(2 * R);
+    for (auto& c : n.res) take_convbn(p, c, (size_t)C * C * 9, C);
+    take_convbn(p, n.pconv, (size_t)KH_POLICY_MID * C, KH_POLICY_MID);
+    n.p2w = take(p, (size_t)KH_POLICY_PLANES * KH_POLICY_MID);
+    n.p2b = take(p, KH_POLICY_PLANES);
+    take_convbn(p, n.vconv, (size_t)C, 1);
+    n.fcw = take(p, (size_t)KH_VALUE_WIDTH * 64);
+    n.fcb = take(p, KH_VALUE_WIDTH);
+    return n;
+}
+
+// One immutable, device-resident parameter set.  kh_load_weights builds a new one and swaps
+// the engine's shared_ptr; calls in flight keep the old set alive until they finish.
+struct Weights {
+    int generation = 0;
+    std::vector<float> blob;             // host copy (kh_clone)
+    DevMem simple;                       // fp32 [tap][ci][co] + scale/shift per layer
+    std::vector<kh::SimpleLayer> layers; // stem, 2R tower convs, policyconv, policyconv2, valueconv
+    const float *fcw = nullptr, *fcb = nullptr;
+};
+
+// Eval-mode BatchNorm folded to an epilogue (scale, shift):
+//   bn(conv + bias) = conv * s + ((bias - mean) * s + beta),  s = gamma / sqrt(var + 1e-5)
+void fold_bn(const ConvBN& c, int co, float* scale, float* shift)
+{
+    for (int i = 0; i < co; ++i) {
+        const float s = c.g[i] / sqrtf(c.rv[i] + 1e-5f);
+        scale[i] = s;
+        shift[i] = (c.b[i] - c.rm[i]) * s + c.be[i];
+    }
+}
+
+int build_simple(Weights& W, const HostNet& n, int F, int C, int R)
+{
+    struct Plan { const float* w; int Ci, Co, taps, relu; const ConvBN* bn; const float* bias; };
+    std::vector<Plan> plan;
+    plan.push_back({ n.stem.w, F, C, 9, 1, &n.stem, nullptr });
+    for (int i = 0; i < 2 * R; ++i) plan.push_back({ n.res[i].w, C, C, 9, 1, &n.res[i], nullptr });
+    plan.push_back({ n.pconv.w, C, KH_POLICY_MID, 1, 1, &n.pconv, nullptr });
+    plan.push_back({ n.p2w, KH_POLICY_MID, KH_POLICY_PLANES, 1, 0, nullptr, n.p2b });
+    plan.push_back({ n.vconv.w, C, 1, 1, 1, &n.vconv, nullptr });
+
+    size_t total = 0;
+    for (auto& p : plan) total += (size_t)p.taps * p.Ci * p.Co + 2 * (size_t)p.Co;
+    total += (size_t)KH_VALUE_WIDTH * 64 + KH_VALUE_WIDTH;
+    std::vector<float> host(total);
+    int rc = W.simple.ensure(total * sizeof(float));
+    if (rc) return rc;
+    float* dbase = W.simple.as<float>();
+    size_t off = 0;
+    for (auto& p : plan) {
+        kh::SimpleLayer L;
+        L.Ci = p.Ci; L.Co = p.Co; L.taps = p.taps; L.relu = p.relu;
+        float* wt = host.data() + off;
+        // libtorch [Co][Ci][kh][kw] -> [tap][Ci][Co]
+        for (int co = 0; co < p.Co; ++co)
+            for (int ci = 0; ci < p.Ci; ++ci)
+                for (int k = 0; k < p.taps; ++k)
+                    wt[((size_t)k * p.Ci + ci) * p.Co + co] = p.w[((size_t)co * p.Ci + ci) * p.taps + k];
+        L.wt = dbase + off;
+        off += (size_t)p.taps * p.Ci * p.Co;
+        float* sc = host.data() + off;
+        float* sh = sc + p.Co;
+        if (p.bn) fold_bn(*p.bn, p.Co, sc, sh);
+        else for (int i = 0; i < p.Co; ++i) { sc[i] = 1.0f; sh[i] = p.bias[i]; }
+        L.scale = dbase + off; L.shift = dbase + off + p.Co;
+        off += 2 * (size_t)p.Co;
+        W.layers.push_back(L);
+    }
+    memcpy(host.data() + off, n.fcw, sizeof(float) * KH_VALUE_WIDTH * 64);
+    W.fcw = dbase + off; off += (size_t)KH_VALUE_WIDTH * 64;
+    memcpy(host.data() + off, n.fcb, sizeof(float) * KH_VALUE_WIDTH);
+    W.fcb = dbase + off; off += KH_VALUE_WIDTH;
+    HIPCHK(hipMemcpy(dbase, host.data(), total * sizeof(float), hipMemcpyHostToDevice));
+    return KH_OK;
+}
+
+// ------------------------------------------------------------------------------- slots
+// Per-call workspace: stream + device scratch.  kh_infer may be called concurrently from many
+// host threads on one engine (nn.cpp:166 takes a shared lock); each call owns one slot.
+struct Slot {
+    hipStream_t stream = nullptr;
+    int cap = 0;                 // boards the scratch is sized for
+    DevMem in, x, t, u, ph, logits, policy, v64, vfull, flags, boards, planes;
+    bool busy = false;
+};
+
+}  // namespace
+
+struct kh_engine {
+    kh_config cfg;
+    std::mutex wmu;
+    std::shared_ptr<Weights> weights;
+    std::mutex smu;
+    std::condition_variable scv;
+    std::vector<std::unique_ptr<Slot>> slots;
+    std::unique_ptr<Slot> devslot;           // scratch for the device-pointer API
+    std::mutex dmu;
+};
+
+namespace {
+
+constexpr int MAX_SLOTS = 8;
+
+int set_device(kh_engine* e) { HIPCHK(hipSetDevice(e->cfg.device)); return KH_OK; }
+
+int slot_ensure(kh_engine* e, Slot& s, int batch, bool host_io)
+{
+    if (!s.stream) HIPCHK(hipStreamCreateWithFlags(&s.stream, hipStreamNonBlocking));
+    if (batch <= s.cap) return KH_OK;
+    const size_t B = batch, C = e->cfg.filters, F = e->cfg.features;
+    int rc = 0;
+    if (host_io) {
+        rc |= s.in.ensure(B * 64 * F * 4);
+        rc |= s.policy.ensure(B * KH_PSIZE * 4);
+        rc |= s.vfull.ensure(B * KH_VALUE_WIDTH * 4);
+        rc |= s.boards.ensure(B * sizeof(kh_board));
+        rc |= s.planes.ensure(B * 64 * KH_NFEATURES * 4);
+    }
+    rc |= s.x.ensure(B * 64 * C * 4);
+    rc |= s.t.ensure(B * 64 * C * 4);
+    rc |= s.u.ensure(B * 64 * C * 4);
+    rc |= s.ph.ensure(B * 64 * KH_POLICY_MID * 4);
+    rc |= s.logits.ensure(B * KH_PSIZE * 4);
+    rc |= s.v64.ensure(B * 64 * 4);
+    rc |= s.flags.ensure(16);
+    if (rc) return KH_ERR_HIP;
+    s.cap = batch;
+    return KH_OK;
+}
+
+struct SlotLease {
+    kh_engine* e;
+    Slot* s = nullptr;
+    explicit SlotLease(kh_engine* e_) : e(e_)
+    {
+        std::unique_lock<std::mutex> lk(e->smu);
+        for (;;) {
+            for (auto& p : e->slots)
+                if (!p->busy) { s = p.get(); break; }
+            if (!s && (int)e->slots.size() < MAX_SLOTS) {
+                e->slots.emplace_back(new Slot());
+                s = e->slots.back().get();
+            }
+            if (s) { s->busy = true; return; }
+            e->scv.wait(lk);
+        }
+    }
+    ~SlotLease()
+    {
+        { std::lock_guard<std::mutex> lk(e->smu); s->busy = false; }
+        e->scv.notify_one();
+    }
+};
+
+std::shared_ptr<Weights> current_weights(kh_engine* e)
+{
+    std::lock_guard<std::mutex> lk(e->wmu);
+    return e->weights;
+}
+
+// The forward pass on device buffers: exact-order fp32 path (forward_simple.hip).
+int forward_simple(kh_engine* e, const Weights& W, Slot& s, const float* d_in, int B,
+                   float* d_policy, float* d_vfull, float* d_logits_out)
+{
+    const int R = e->cfg.residuals;
+    hipStream_t st = s.stream;
+    float *x = s.x.as<float>(), *t = s.t.as<float>(), *u = s.u.as<float>();
+    int* flags = s.flags.as<int>();
+    HIPCHK(hipMemsetAsync(flags, 0, 16, st));
+    size_t li = 0;
+    kh::launch_simple_conv(W.layers[li++], d_in, nullptr, x, B, st);            // nn.cpp:62-65
+    for (int r = 0; r < R; ++r) {                                              // nn.cpp:26-34
+        kh::launch_simple_conv(W.layers[li++], x, nullptr, t, B, st);
+        kh::launch_simple_conv(W.layers[li++], t, x, u, B, st);
+        float* tmp = x; x = u; u = tmp;
+    }
+    float* logits = d_logits_out ? d_logits_out : s.logits.as<float>();
+    kh::launch_simple_conv(W.layers[li++], x, nullptr, s.ph.as<float>(), B, st);       // nn.cpp:72-74
+    kh::launch_simple_conv(W.layers[li++], s.ph.as<float>(), nullptr, logits, B, st);  // nn.cpp:75-79
+    kh::launch_softmax4672(logits, d_policy, B, flags, st);                            // nn.cpp:80
+    kh::launch_simple_conv(W.layers[li++], x, nullptr, s.v64.as<float>(), B, st);      // nn.cpp:83-85
+    kh::launch_value_fc(s.v64.as<float>(), W.fcw, W.fcb, d_vfull, B, flags, st);        // nn.cpp:86-88
+    HIPCHK(hipGetLastError());
+    return KH_OK;
+}
+
+int forward_dispatch(kh_engine* e, const Weights& W, Slot& s, const float* d_in, int B,
+                     float* d_policy, float* d_vfull, float* d_logits_out)
+{
+    switch (e->cfg.dtype) {
+    case KH_F32: return forward_simple(e, W, s, d_in, B, d_policy, d_vfull, d_logits_out);
+    default: return fail(KH_ERR_INVALID, "dtype %d not built into this library", e->cfg.dtype);
+    }
+}
+
+int check_cfg(const kh_config* c)
+{
+    if (!c) return fail(KH_ERR_INVALID, "null config");
+    if (c->width != KH_WIDTH || c->height != KH_HEIGHT)
+        return fail(KH_ERR_INVALID, "only 8x8 boards are supported (got %dx%d)", c->width, c->height);
+    if (c->psize != KH_PSIZE) return fail(KH_ERR_INVALID, "psize must be %d", KH_PSIZE);
+    if (c->features < 1 || c->features > 4096) return fail(KH_ERR_INVALID, "bad features %d", c->features);
+    if (c->filters < 1 || c->filters > 1024) return fail(KH_ERR_INVALID, "bad filters %d", c->filters);
+    if (c->residuals < 0 || c->residuals > 256) return fail(KH_ERR_INVALID, "bad residuals %d", c->residuals);
+    if (c->dtype != KH_F32 && c->dtype != KH_BF16 && c->dtype != KH_F16)
+        return fail(KH_ERR_INVALID, "bad dtype %d", c->dtype);
+    if (c->value_mode != KH_VALUE_REFERENCE_FLAT && c->value_mode != KH_VALUE_PER_SAMPLE0)
+        return fail(KH_ERR_INVALID, "bad value_mode %d", c->value_mode);
+    return KH_OK;
+}
+
+int infer_host(kh_engine* e, const float* input, const kh_board* boards, int batch,
+               float* policy, float* value, float* value_full, float* logits)
+{
+    if (!e) return fail(KH_ERR_INVALID, "null engine");
+    if (batch < 1) return fail(KH_ERR_INVALID, "batch must be >= 1 (got %d)", batch);
+    if ((!input && !boards) || !policy) return fail(KH_ERR_INVALID, "null buffer");
+    std::shared_ptr<Weights> W = current_weights(e);
+    if (!W) return fail(KH_ERR_NO_WEIGHTS, "kh_infer before kh_load_weights");
+    int rc = set_device(e);
+    if (rc) return rc;
+    SlotLease lease(e);
+    Slot& s = *lease.s;
+    if ((rc = slot_ensure(e, s, batch, true))) return rc;
+    const size_t B = batch, F = e->cfg.features;
+    hipStream_t st = s.stream;
+    const float* d_in;
+    if (boards) {
+        HIPCHK(hipMemcpyAsync(s.boards.p, boards, B * sizeof(kh_board), hipMemcpyHostToDevice, st));
+        kh::launch_encode_f32(s.boards.as<kh_board>(), batch, s.planes.as<float>(), st);
+        d_in = s.planes.as<float>();
+    } else {
+        HIPCHK(hipMemcpyAsync(s.in.p, input, B * 64 * F * 4, hipMemcpyHostToDevice, st));   // nn.cpp:160
+        d_in = s.in.as<float>();
+    }
+    float* d_logits = logits ? s.logits.as<float>() : nullptr;
+    if ((rc = forward_dispatch(e, *W, s, d_in, batch, s.policy.as<float>(), s.vfull.as<float>(), d_logits)))
+        return rc;
+    int flags[4] = { 0, 0, 0, 0 };
+    HIPCHK(hipMemcpyAsync(policy, s.policy.p, B * KH_PSIZE * 4, hipMemcpyDeviceToHost, st));  // nn.cpp:173,185
+    if (logits) HIPCHK(hipMemcpyAsync(logits, s.logits.p, B * KH_PSIZE * 4, hipMemcpyDeviceToHost, st));
+    if (value_full)
+        HIPCHK(hipMemcpyAsync(value_full, s.vfull.p, B * KH_VALUE_WIDTH * 4, hipMemcpyDeviceToHost, st));
+    if (value) {
+        if (e->cfg.value_mode == KH_VALUE_REFERENCE_FLAT)
+            // nn.cpp:186: the first `batch` floats of the flattened [batch,256] tensor
+            HIPCHK(hipMemcpyAsync(value, s.vfull.p, B * 4, hipMemcpyDeviceToHost, st));
+        else
+            HIPCHK(hipMemcpy2DAsync(value, 4, s.vfull.p, KH_VALUE_WIDTH * 4, 4, B, hipMemcpyDeviceToHost, st));
+    }
+    HIPCHK(hipMemcpyAsync(flags, s.flags.p, 16, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    if (flags[0]) return fail(KH_ERR_NAN_POLICY, "inference policy output contains NaN");   // nn.cpp:176-177
+    if (flags[1]) return fail(KH_ERR_NAN_VALUE, "inference value output contains NaN");     // nn.cpp:179-180
+    return KH_OK;
+}
+
+}  // namespace
+
+// =============================================================================== C ABI
+extern "C" {
+
+const char* kh_last_error(void) { return g_err.c_str(); }
+const char* kh_version(void) { return "kamihip 0.1 gfx950"; }
+
+int kh_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+size_t kh_weight_count(int F, int C, int R)
+{
+    size_t n = 0;
+    n += (size_t)C * F * 9 + C + 4 * (size_t)C;
+    n += (size_t)R * 2 * ((size_t)C * C * 9 + C + 4 * (size_t)C);
+    n += (size_t)KH_POLICY_MID * C + KH_POLICY_MID + 4 * KH_POLICY_MID;
+    n += (size_t)KH_POLICY_PLANES * KH_POLICY_MID + KH_POLICY_PLANES;
+    n += (size_t)C + 1 + 4;
+    n += (size_t)KH_VALUE_WIDTH * 64 + KH_VALUE_WIDTH;
+    return n;
+}
+
+int kh_create(const kh_config* cfg, kh_engine** out)
+{
+    if (!out) return fail(KH_ERR_INVALID, "null out");
+    *out = nullptr;
+    int rc = check_cfg(cfg);
+    if (rc) return rc;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+        return fail(KH_ERR_NO_DEVICE, "no HIP device visible; this engine has no CPU path");
+    if (cfg->device < 0 || cfg->device >= ndev)
+        return fail(KH_ERR_INVALID, "device %d out of range (%d visible)", cfg->device, ndev);
+    hipDeviceProp_t prop;
+    HIPCHK(hipGetDeviceProperties(&prop, cfg->device));
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+        return fail(KH_ERR_NO_DEVICE, "device %d is %s; this library is built for gfx950 only",
+                    cfg->device, prop.gcnArchName);
+    kh_engine* e = new kh_engine();
+    e->cfg = *cfg;
+    *out = e;
+    return KH_OK;
+}
+
+void kh_destroy(kh_engine* e)
+{
+    if (!e) return;
+    (void)hipSetDevice(e->cfg.device);
+    auto kill = [](Slot* s) { if (s && s->stream) { (void)hipStreamSynchronize(s->stream); (void)hipStreamDestroy(s->stream); } };
+    for (auto& s : e->slots) kill(s.get());
+    kill(e->devslot.get());
+    delete e;
+}
+
+int kh_load_weights(kh_engine* e, const float* blob, size_t nfloats, int generation)
+{
+    if (!e || !blob) return fail(KH_ERR_INVALID, "null argument");
+    const int F = e->cfg.features, C = e->cfg.filters, R = e->cfg.residuals;
+    if (nfloats != kh_weight_count(F, C, R))
+        return fail(KH_ERR_INVALID, "weight blob has %zu floats, expected %zu for F=%d C=%d R=%d",
+                    nfloats, kh_weight_count(F, C, R), F, C, R);
+    int rc = set_device(e);
+    if (rc) return rc;
+    auto W = std::make_shared<Weights>();
+    W->generation = generation;
+    W->blob.assign(blob, blob + nfloats);
+    HostNet n = parse_blob(W->blob.data(), F, C, R);
+    if ((rc = build_simple(*W, n, F, C, R))) return rc;
+    std::lock_guard<std::mutex> lk(e->wmu);
+    e->weights = W;                  // calls in flight keep their own reference
+    return KH_OK;
+}
+
+int kh_generation(kh_engine* e)
+{
+    if (!e) return -1;
+    auto W = current_weights(e);
+    return W ? W->generation : 0;
+}
+
+int kh_clone(kh_engine* src, kh_engine** out)
+{
+    if (!src || !out) return fail(KH_ERR_INVALID, "null argument");
+    int rc = kh_create(&src->cfg, out);
+    if (rc) return rc;
+    auto W = current_weights(src);
+    if (W && (rc = kh_load_weights(*out, W->blob.data(), W->blob.size(), W->generation))) {
+        kh_destroy(*out);
+        *out = nullptr;
+        return rc;
+    }
+    return KH_OK;
+}
+
+int kh_infer(kh_engine* e, const float* input, int batch, float* policy, float* value)
+{
+    if (!value) return fail(KH_ERR_INVALID, "null value buffer");
+    return infer_host(e, input, nullptr, batch, policy, value, nullptr, nullptr);
+}
+
+int kh_infer_full(kh_engine* e, const float* input, int batch, float* policy, float* value_full,
+                  float* logits)
+{
+    return infer_host(e, input, nullptr, batch, policy, nullptr, value_full, logits);
+}
+
+int kh_encode_infer(kh_engine* e, const kh_board* boards, int batch, float* policy, float* value)
+{
+    if (!e) return fail(KH_ERR_INVALID, "null engine");
+    if (e->cfg.features != KH_NFEATURES)
+        return fail(KH_ERR_INVALID, "kh_encode_infer needs features == %d (Env::observe planes)", KH_NFEATURES);
+    if (!value || !boards) return fail(KH_ERR_INVALID, "null buffer");
+    return infer_host(e, nullptr, boards, batch, policy, value, nullptr, nullptr);
+}
+
+int kh_encode(kh_engine* e, const kh_board* boards, int batch, float* planes)
+{
+    if (!e || !boards || !planes) return fail(KH_ERR_INVALID, "null argument");
+    if (batch < 0) return fail(KH_ERR_INVALID, "negative batch");
+    if (batch == 0) return KH_OK;
+    int rc = set_device(e);
+    if (rc) return rc;
+    SlotLease lease(e);
+    Slot& s = *lease.s;
+    if (!s.stream) HIPCHK(hipStreamCreateWithFlags(&s.stream, hipStreamNonBlocking));
+    const size_t B = batch;
+    if (s.boards.ensure(B * sizeof(kh_board)) || s.planes.ensure(B * 64 * KH_NFEATURES * 4)) return KH_ERR_HIP;
+    HIPCHK(hipMemcpyAsync(s.boards.p, boards, B * sizeof(kh_board), hipMemcpyHostToDevice, s.stream));
+    kh::launch_encode_f32(s.boards.as<kh_board>(), batch, s.planes.as<float>(), s.stream);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(planes, s.planes.p, B * 64 * KH_NFEATURES * 4, hipMemcpyDeviceToHost, s.stream));
+    HIPCHK(hipStreamSynchronize(s.stream));
+    return KH_OK;
+}
+
+static int dev_slot(kh_engine* e, int batch, void* stream, Slot** out)
+{
+    if (!e->devslot) e->devslot.reset(new Slot());
+    Slot& s = *e->devslot;
+    int rc = slot_ensure(e, s, batch, false);
+    if (rc) return rc;
+    *out = &s;
+    (void)stream;
+    return KH_OK;
+}
+
+int kh_infer_device(kh_engine* e, const void* d_input, int batch, float* d_policy,
+                    float* d_value_full, void* stream)
+{
+    if (!e || !d_input || !d_policy || !d_value_full) return fail(KH_ERR_INVALID, "null argument");
+    if (batch < 1) return fail(KH_ERR_INVALID, "batch must be >= 1");
+    auto W = current_weights(e);
+    if (!W) return fail(KH_ERR_NO_WEIGHTS, "kh_infer_device before kh_load_weights");
+    int rc = set_device(e);
+    if (rc) return rc;
+    std::lock_guard<std::mutex> lk(e->dmu);
+    Slot* s;
+    if ((rc = dev_slot(e, batch, stream, &s))) return rc;
+    // run on the caller's stream when given; scratch is then ordered by that stream
+    hipStream_t own = s->stream;
+    if (stream) s->stream = static_cast<hipStream_t>(stream);
+    rc = forward_dispatch(e, *W, *s, static_cast<const float*>(d_input), batch, d_policy, d_value_full, nullptr);
+    s->stream = own;
+    return rc;
+}
+
+int kh_encode_device(kh_engine* e, const kh_board* d_boards, int batch, float* d_planes, void* stream)
+{
+    if (!e || !d_boards || !d_planes) return fail(KH_ERR_INVALID, "null argument");
+    if (batch < 1) return fail(KH_ERR_INVALID, "batch must be >= 1");
+    int rc = set_device(e);
+    if (rc) return rc;
+    std::lock_guard<std::mutex> lk(e->dmu);
+    if (!e->devslot) e->devslot.reset(new Slot());
+    Slot& s = *e->devslot;
+    if (!s.stream) HIPCHK(hipStreamCreateWithFlags(&s.stream, hipStreamNonBlocking));
+    kh::launch_encode_f32(d_boards, batch, d_planes, stream ? static_cast<hipStream_t>(stream) : s.stream);
+    HIPCHK(hipGetLastError());
+    return KH_OK;
+}
+
+static int time_loop(kh_engine* e, int iters, float* ms, int (*body)(void*), void* ctx)
+{
+    if (iters < 1 || !ms) return fail(KH_ERR_INVALID, "bad timing arguments");
+    int rc = set_device(e);
+    if (rc) return rc;
+    if (!e->devslot) e->devslot.reset(new Slot());
+    Slot& s = *e->devslot;
+    if (!s.stream) HIPCHK(hipStreamCreateWithFlags(&s.stream, hipStreamNonBlocking));
+    hipEvent_t t0, t1;
+    HIPCHK(hipEventCreate(&t0));
+    HIPCHK(hipEventCreate(&t1));
+    if ((rc = body(ctx))) return rc;                       // warm-up (sizes scratch)
+    HIPCHK(hipStreamSynchronize(s.stream));
+    HIPCHK(hipEventRecord(t0, s.stream));
+    for (int i = 0; i < iters; ++i)
+        if ((rc = body(ctx))) return rc;
+    HIPCHK(hipEventRecord(t1, s.stream));
+    HIPCHK(hipEventSynchronize(t1));
+    float total = 0.f;
+    HIPCHK(hipEventElapsedTime(&total, t0, t1));
+    *ms = total / iters;
+    (void)hipEventDestroy(t0);
+    (void)hipEventDestroy(t1);
+    return KH_OK;
+}
+
+struct InferCtx { kh_engine* e; const void* in; int B; float *p, *v; };
+struct EncCtx { kh_engine* e; const kh_board* b; int B; float* planes; };
+
+int kh_time_infer_device(kh_engine* e, const void* d_input, int batch, float* d_policy,
+                         float* d_value_full, int iters, float* ms_per_launch)
+{
+    if (!e) return fail(KH_ERR_INVALID, "null engine");
+    InferCtx c{ e, d_input, batch, d_policy, d_value_full };
+    return time_loop(e, iters, ms_per_launch,
+                     [](void* p) { auto* c = static_cast<InferCtx*>(p); return kh_infer_device(c->e, c->in, c->B, c->p, c->v, nullptr); }, &c);
+}
+
+int kh_time_encode_device(kh_engine* e, const kh_board* d_boards, int batch, float* d_planes,
+                          int iters, float* ms_per_launch)
+{
+    if (!e) return fail(KH_ERR_INVALID, "null engine");
+    EncCtx c{ e, d_boards, batch, d_planes };
+    return time_loop(e, iters, ms_per_launch,
+                     [](void* p) { auto* c = static_cast<EncCtx*>(p); return kh_encode_device(c->e, c->b, c->B, c->planes, nullptr); }, &c);
+}
+
+int kh_dev_alloc(kh_engine* e, size_t bytes, void** d_ptr)
+{
+    if (!e || !d_ptr) return fail(KH_ERR_INVALID, "null argument");
+    int rc = set_device(e);
+    if (rc) return rc;
+    HIPCHK(hipMalloc(d_ptr, bytes));
+    return KH_OK;
+}
+int kh_dev_free(kh_engine* e, void* d_ptr)
+{
+    if (!e) return fail(KH_ERR_INVALID, "null engine");
+    int rc = set_device(e);
+    if (rc) return rc;
+    HIPCHK(hipFree(d_ptr));
+    return KH_OK;
+}
+int kh_memcpy_h2d(kh_engine* e, void* d_dst, const void* h_src, size_t bytes)
+{
+    if (!e) return fail(KH_ERR_INVALID, "null engine");
+    int rc = set_device(e);
+    if (rc) return rc;
+    HIPCHK(hipMemcpy(d_dst, h_src, bytes, hipMemcpyHostToDevice));
+    return KH_OK;
+}
+int kh_memcpy_d2h(kh_engine* e, void* h_dst, const void* d_src, size_t bytes)
+{
+    if (!e) return fail(KH_ERR_INVALID, "null engine");
+    int rc = set_device(e);
+    if (rc) return rc;
+    HIPCHK(hipMemcpy(h_dst, d_src, bytes, hipMemcpyDeviceToHost));
+    return KH_OK;
+}
+int kh_sync(kh_engine* e)
+{
+    if (!e) return fail(KH_ERR_INVALID, "null engine");
+    int rc = set_device(e);
+    if (rc) return rc;
+    HIPCHK(hipDeviceSynchronize());
+    return KH_OK;
+}
+
+}  // extern "C"

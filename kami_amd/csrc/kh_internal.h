@@ -1,0 +1,35 @@
+// kh_internal.h — declarations shared by the translation units of libkamihip.so.
+// Not part of the public boundary (that is include/kami_hip.h).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+#include <stdint.h>
+
+#include "../../include/kami_hip.h"
+
+namespace kh {
+
+// ---- encode.hip -------------------------------------------------------------------------
+// Env::observe (kami/env.h:202-262) for n records -> fp32 planes [n][8][8][30].
+void launch_encode_f32(const kh_board* d_boards, int n, float* d_planes, hipStream_t s);
+
+// ---- forward_simple.hip -----------------------------------------------------------------
+// Plain fp32 VALU kernels, one launch per layer.  Exact-order fp32 (same tap-major,
+// channel-inner accumulation order as the CPU oracle); the correctness anchor on device.
+struct SimpleLayer {            // device pointers
+    const float* wt;            // [taps][Ci][Co]
+    const float* scale;         // [Co]  gamma / sqrt(var + eps)            (1 for plain conv)
+    const float* shift;         // [Co]  (bias - mean) * scale + beta       (bias for plain conv)
+    int Ci, Co, taps;           // taps = 9 (3x3 pad 1) or 1
+    int relu;
+};
+// out = (skip ? skip : 0) + act(conv(in) * scale + shift); activations [B][64][C] fp32
+void launch_simple_conv(const SimpleLayer& L, const float* in, const float* skip, float* out,
+                        int B, hipStream_t s);
+// logits [B][4672] -> policy = exp(log_softmax(logits)) (nn.cpp:80); sets flags[0] on NaN
+void launch_softmax4672(const float* logits, float* policy, int B, int* flags, hipStream_t s);
+// v64 [B][64] -> value_full [B][256] = tanh(v64 W^T + b) (nn.cpp:86-88); sets flags[1] on NaN
+void launch_value_fc(const float* v64, const float* fcw, const float* fcb, float* value_full,
+                     int B, int* flags, hipStream_t s);
+
+}  // namespace kh

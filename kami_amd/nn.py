@@ -1,0 +1,149 @@
+"""Host-side mirror of the reference's evaluator class, over the C ABI.
+
+`NN` keeps the method set and argument meaning of `kami::NN` (kami/nn/nn.h:40-73):
+`NN(width, height, features, psize)`, `infer`, `read`, `write`, `get_generation`, `isCUDA`,
+`obsize`, `polsize`, `clone`; the two option keys the reference's module reads
+(`filters`, `residuals`, nn.cpp:42-43) are explicit constructor arguments here.
+`infer` raises RuntimeError with the reference's messages on NaN outputs (nn.cpp:176-180).
+The C++ twin used to drop into kami.cpp is kami_amd/host/nn.h.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional
+
+import numpy as np
+
+from . import _lib as L
+from . import weights as W
+
+PSIZE = 4672
+NFEATURES = 30
+OBSIZE = 8 * 8 * NFEATURES
+VALUE_WIDTH = 256
+
+
+class KamiError(RuntimeError):
+    def __init__(self, status: int, msg: str):
+        super().__init__(msg)
+        self.status = status
+
+
+def _chk(rc: int) -> None:
+    if rc != L.KH_OK:
+        raise KamiError(rc, L.last_error())
+
+
+def _ptr(a: np.ndarray):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+class NN:
+    def __init__(self, width: int = 8, height: int = 8, features: int = NFEATURES,
+                 psize: int = PSIZE, *, filters: int = 256, residuals: int = 2,
+                 dtype: str = "f32", value_mode: int = L.KH_VALUE_REFERENCE_FLAT,
+                 device: int = 0):
+        self._lib = L.load()
+        self.cfg = L.Config(width=width, height=height, features=features, psize=psize,
+                            filters=filters, residuals=residuals, dtype=L.DTYPES[dtype],
+                            value_mode=value_mode, device=device)
+        self.dtype = dtype
+        self._h = C.c_void_p()
+        _chk(self._lib.kh_create(C.byref(self.cfg), C.byref(self._h)))
+
+    # -- kami::NN surface ---------------------------------------------------------------
+    def get_generation(self) -> int:
+        return self._lib.kh_generation(self._h)
+
+    def isCUDA(self) -> bool:            # nn.h:62 — true: the engine only exists on the GPU
+        return True
+
+    def obsize(self) -> int:
+        return self.cfg.width * self.cfg.height * self.cfg.features
+
+    def polsize(self) -> int:
+        return self.cfg.psize
+
+    def infer(self, input: np.ndarray, batch: Optional[int] = None,
+              policy: Optional[np.ndarray] = None, value: Optional[np.ndarray] = None):
+        """nn.cpp:155-187.  input [batch,8,8,F] fp32 -> (policy [batch,4672], value [batch])."""
+        x = np.ascontiguousarray(input, dtype=np.float32)
+        if batch is None:
+            batch = x.size // self.obsize()
+        if x.size != batch * self.obsize():
+            raise ValueError("input size does not match batch * obsize()")
+        if policy is None:
+            policy = np.empty((batch, PSIZE), np.float32)
+        if value is None:
+            value = np.empty((batch,), np.float32)
+        _chk(self._lib.kh_infer(self._h, _ptr(x), batch, _ptr(policy), _ptr(value)))
+        return policy, value
+
+    def read(self, path: str) -> None:
+        blob, F, Cc, R, gen = W.load(path)
+        if (F, Cc, R) != (self.cfg.features, self.cfg.filters, self.cfg.residuals):
+            raise KamiError(L.KH_ERR_INVALID, "checkpoint shape does not match this NN")
+        self.load_weights(blob, gen)
+
+    def write(self, path: str) -> None:
+        if self._blob is None:
+            raise KamiError(L.KH_ERR_NO_WEIGHTS, "no weights loaded")
+        W.save(path, self._blob, self.cfg.features, self.cfg.filters, self.cfg.residuals,
+               self.get_generation())
+
+    def clone(self) -> "NN":
+        other = object.__new__(NN)
+        other._lib, other.cfg, other.dtype = self._lib, self.cfg, self.dtype
+        other._blob = self._blob
+        other._h = C.c_void_p()
+        _chk(self._lib.kh_clone(self._h, C.byref(other._h)))
+        return other
+
+    # -- engine extras ------------------------------------------------------------------
+    _blob: Optional[np.ndarray] = None
+
+    def load_weights(self, blob: np.ndarray, generation: int = 0) -> None:
+        blob = np.ascontiguousarray(blob, dtype=np.float32)
+        _chk(self._lib.kh_load_weights(self._h, _ptr(blob), blob.size, generation))
+        self._blob = blob
+
+    def infer_full(self, input: np.ndarray, want_logits: bool = True):
+        """-> (policy [B,4672], value_full [B,256], logits [B,4672] or None)"""
+        x = np.ascontiguousarray(input, dtype=np.float32)
+        batch = x.size // self.obsize()
+        policy = np.empty((batch, PSIZE), np.float32)
+        vfull = np.empty((batch, VALUE_WIDTH), np.float32)
+        logits = np.empty((batch, PSIZE), np.float32) if want_logits else None
+        _chk(self._lib.kh_infer_full(self._h, _ptr(x), batch, _ptr(policy), _ptr(vfull),
+                                     _ptr(logits) if want_logits else None))
+        return policy, vfull, logits
+
+    def encode(self, boards: np.ndarray) -> np.ndarray:
+        """Env::observe (env.h:202-262) for kh_board records -> [n,8,8,30] fp32."""
+        b = np.ascontiguousarray(boards, dtype=L.BOARD_DTYPE)
+        out = np.empty((b.shape[0], 8, 8, NFEATURES), np.float32)
+        _chk(self._lib.kh_encode(self._h, _ptr(b), b.shape[0], _ptr(out)))
+        return out
+
+    def encode_infer(self, boards: np.ndarray):
+        b = np.ascontiguousarray(boards, dtype=L.BOARD_DTYPE)
+        n = b.shape[0]
+        policy = np.empty((n, PSIZE), np.float32)
+        value = np.empty((n,), np.float32)
+        _chk(self._lib.kh_encode_infer(self._h, _ptr(b), n, _ptr(policy), _ptr(value)))
+        return policy, value
+
+    @property
+    def handle(self):
+        return self._h
+
+    def close(self) -> None:
+        if getattr(self, "_h", None):
+            self._lib.kh_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

@@ -1,0 +1,210 @@
+"""Parity tests proper: the HIP path (through the C ABI) against the golden fixtures produced by
+the unmodified reference, and against the CPU oracle on seeded inputs.  Run with -m gpu."""
+import numpy as np
+import pytest
+
+from kami_amd import NN, KamiError, _lib as L, weights as W
+from oracle import pyoracle as ko
+
+pytestmark = pytest.mark.gpu
+
+# Tolerances per arithmetic type, vs the fp32 reference (SURVEY §8c tolerance anchors).
+# logp = log-probabilities (differences of pre-softmax logits), value = tanh output.
+TOL = {
+    "f32": dict(logp=3e-4, prob_rtol=3e-4, value=3e-5),
+    "f16": dict(logp=3e-2, prob_rtol=3e-2, value=2e-3),
+    "bf16": dict(logp=2e-1, prob_rtol=2e-1, value=1.5e-2),
+}
+
+
+def make_nn(d, dtype="f32", **kw):
+    nn = NN(8, 8, d["features"], 4672, filters=d["filters"], residuals=d["residuals"], dtype=dtype, **kw)
+    nn.load_weights(d["blob"], d["generation"])
+    return nn
+
+
+def random_boards(n, seed):
+    """Synthetic records covering every field the encoder reads (not necessarily legal chess)."""
+    rng = np.random.default_rng(seed)
+    b = np.zeros(n, dtype=L.BOARD_DTYPE)
+    # each square: empty (p=.5) or one of 12 pieces
+    code = rng.integers(-12, 12, size=(n, 64))
+    for t in range(6):
+        for col in range(2):
+            m = (code == 2 * t + col)
+            bits = (m.astype(np.uint64) << np.arange(64, dtype=np.uint64)).sum(1, dtype=np.uint64)
+            b["piece_occ"][:, t] |= bits
+            b["color_occ"][:, col] |= bits
+    b["ply"] = rng.integers(0, 70000, n)
+    b["halfmove_clock"] = rng.integers(0, 200, n)
+    b["ctm"] = rng.integers(0, 2, n)
+    b["castle_rights"] = rng.integers(0, 16, n)
+    return b
+
+
+# ------------------------------------------------------------------------------ encoding
+def test_encode_fixture_bit_exact(observe_fixture):
+    f = observe_fixture
+    boards = ko.boards_from_fens([s.decode() for s in f["fen"]], f["ply"])
+    nn = NN(filters=8, residuals=0)
+    got = nn.encode(boards).reshape(len(boards), -1)
+    want = f["obs"].astype(np.float32)
+    assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
+
+
+@pytest.mark.parametrize("n", [1, 3, 4, 5, 1000, 200003])
+def test_encode_random_boards_vs_oracle(n):
+    boards = random_boards(n, seed=n)
+    nn = NN(filters=8, residuals=0)
+    got = nn.encode(boards)
+    want = ko.observe(boards)
+    assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
+
+
+def test_encode_empty_batch():
+    nn = NN(filters=8, residuals=0)
+    out = nn.encode(np.zeros(0, dtype=L.BOARD_DTYPE))
+    assert out.shape == (0, 8, 8, 30)
+
+
+# ------------------------------------------------------------------------------ forward
+def check_forward(nn, d, dtype):
+    tol = TOL[dtype]
+    policy, vfull, logits = nn.infer_full(d["x"])
+    rows = d["policy_rows"]
+    assert np.allclose(policy.sum(1), 1.0, atol=1e-3)
+    np.testing.assert_allclose(np.log(policy[rows]), np.log(d["policy"]), atol=tol["logp"], rtol=0)
+    big = d["policy"] > 1e-6
+    np.testing.assert_allclose(policy[rows][big], d["policy"][big], rtol=tol["prob_rtol"])
+    np.testing.assert_allclose(vfull, d["value_full"], atol=tol["value"], rtol=0)
+    # logits vs the oracle's logits (the reference does not expose them)
+    _, _, ologits = ko.forward(d["blob"], d["features"], d["filters"], d["residuals"], d["x"])
+    np.testing.assert_allclose(logits, ologits, atol=tol["logp"], rtol=0)
+
+
+def test_forward_f32_vs_reference_fixtures(net_fixture):
+    nn = make_nn(net_fixture, "f32")
+    check_forward(nn, net_fixture, "f32")
+
+
+def test_infer_reference_value_copyout(net_fixture):
+    """value[i] = flattened [B,256] tensor element i (nn.cpp:186)."""
+    d = net_fixture
+    nn = make_nn(d, "f32")
+    policy, value = nn.infer(d["x"])
+    np.testing.assert_allclose(value, d["value"], atol=TOL["f32"]["value"], rtol=0)
+    nn2 = make_nn(d, "f32", value_mode=L.KH_VALUE_PER_SAMPLE0)
+    _, v0 = nn2.infer(d["x"])
+    np.testing.assert_allclose(v0, d["value_full"][:, 0], atol=TOL["f32"]["value"], rtol=0)
+
+
+@pytest.mark.parametrize("F,C,R,B", [(119, 64, 6, 48), (30, 64, 6, 16), (30, 24, 1, 7), (119, 128, 2, 5)])
+def test_forward_f32_vs_oracle_bigger_nets(F, C, R, B):
+    blob = W.random_weights(F, C, R, seed=F + C + R, peaky=20.0)
+    x = np.random.default_rng(B).random((B, 8, 8, F), dtype=np.float32)
+    nn = NN(8, 8, F, 4672, filters=C, residuals=R, dtype="f32")
+    nn.load_weights(blob, 1)
+    p, vf, lg = nn.infer_full(x)
+    op, ovf, olg = ko.forward(blob, F, C, R, x)
+    np.testing.assert_allclose(lg, olg, atol=TOL["f32"]["logp"], rtol=0)
+    np.testing.assert_allclose(np.log(p), np.log(op), atol=TOL["f32"]["logp"], rtol=0)
+    np.testing.assert_allclose(vf, ovf, atol=TOL["f32"]["value"], rtol=0)
+
+
+def test_batch_sizes_and_row_independence():
+    """infer must take any batch >= 1 (evaluate.cpp:136-151) and rows must not interact."""
+    F, C, R = 30, 16, 1
+    blob = W.random_weights(F, C, R, seed=2, peaky=10.0)
+    nn = NN(8, 8, F, 4672, filters=C, residuals=R, dtype="f32")
+    nn.load_weights(blob, 1)
+    x = np.random.default_rng(0).random((513, 8, 8, F), dtype=np.float32)
+    p_all, vf_all, _ = nn.infer_full(x, want_logits=False)
+    for b in (1, 2, 63, 257):
+        p, vf, _ = nn.infer_full(x[:b], want_logits=False)
+        assert np.array_equal(p, p_all[:b]) and np.array_equal(vf, vf_all[:b])
+
+
+def test_encode_infer_equals_encode_then_infer(observe_fixture):
+    f = observe_fixture
+    boards = ko.boards_from_fens([s.decode() for s in f["fen"][:40]], f["ply"][:40])
+    F, C, R = 30, 16, 1
+    nn = NN(8, 8, F, 4672, filters=C, residuals=R, dtype="f32")
+    nn.load_weights(W.random_weights(F, C, R, seed=8, peaky=10.0), 3)
+    p1, v1 = nn.encode_infer(boards)
+    p2, v2 = nn.infer(nn.encode(boards))
+    assert np.array_equal(p1, p2) and np.array_equal(v1, v2)
+
+
+# ------------------------------------------------------------------------------ boundary behaviour
+def test_nan_guard_and_errors():
+    F, C, R = 30, 8, 0
+    nn = NN(8, 8, F, 4672, filters=C, residuals=R)
+    x = np.random.default_rng(0).random((2, 8, 8, F), dtype=np.float32)
+    with pytest.raises(KamiError) as ei:
+        nn.infer(x)
+    assert ei.value.status == L.KH_ERR_NO_WEIGHTS
+    blob = W.random_weights(F, C, R, seed=3)
+    nn.load_weights(blob, 1)
+    nn.infer(x)
+    xb = x.copy()
+    xb[1, 0, 0, 0] = np.nan
+    with pytest.raises(KamiError) as ei:
+        nn.infer(xb)
+    assert ei.value.status == L.KH_ERR_NAN_POLICY
+    assert str(ei.value) == "inference policy output contains NaN"       # nn.cpp:177
+    # NaN only in the value head: poison valuefc.bias
+    d = W.split(blob.copy(), F, C, R)
+    d["valuefc.bias"][5] = np.nan
+    nn.load_weights(np.concatenate([v.ravel() for v in d.values()]), 2)
+    with pytest.raises(KamiError) as ei:
+        nn.infer(x)
+    assert ei.value.status == L.KH_ERR_NAN_VALUE
+    assert str(ei.value) == "inference value output contains NaN"        # nn.cpp:180
+    with pytest.raises(KamiError):
+        nn.load_weights(blob[:-1], 1)
+
+
+def test_generation_clone_and_hot_swap(tmp_path):
+    F, C, R = 30, 8, 1
+    nn = NN(8, 8, F, 4672, filters=C, residuals=R)
+    assert nn.get_generation() == 0
+    b1 = W.random_weights(F, C, R, seed=1, peaky=10.0)
+    b2 = W.random_weights(F, C, R, seed=2, peaky=10.0)
+    x = np.random.default_rng(0).random((4, 8, 8, F), dtype=np.float32)
+    nn.load_weights(b1, 5)
+    assert nn.get_generation() == 5
+    p1, v1 = nn.infer(x)
+    twin = nn.clone()                      # NN(NN* other) nn.cpp:130-153
+    nn.load_weights(b2, 6)
+    p2, _ = nn.infer(x)
+    pc, vc = twin.infer(x)
+    assert twin.get_generation() == 5 and nn.get_generation() == 6
+    assert np.array_equal(pc, p1) and np.array_equal(vc, v1) and not np.array_equal(p2, p1)
+    # write -> read -> infer is bit-identical (test/nndisk.cpp:8-29)
+    path = str(tmp_path / "m.bin")
+    nn.write(path)
+    other = NN(8, 8, F, 4672, filters=C, residuals=R)
+    other.read(path)
+    p3, _ = other.infer(x)
+    assert other.get_generation() == 6 and np.array_equal(p3, p2)
+
+
+def test_concurrent_infer_threads():
+    """infer is called concurrently by inference threads on one model (nn.cpp:166)."""
+    import threading
+    F, C, R = 30, 16, 1
+    nn = NN(8, 8, F, 4672, filters=C, residuals=R)
+    nn.load_weights(W.random_weights(F, C, R, seed=4, peaky=10.0), 1)
+    xs = [np.random.default_rng(i).random((8 + i, 8, 8, F), dtype=np.float32) for i in range(6)]
+    want = [nn.infer(x) for x in xs]
+    got = [None] * len(xs)
+
+    def work(i):
+        for _ in range(5):
+            got[i] = nn.infer(xs[i])
+
+    th = [threading.Thread(target=work, args=(i,)) for i in range(len(xs))]
+    [t.start() for t in th]
+    [t.join() for t in th]
+    for g, w in zip(got, want):
+        assert np.array_equal(g[0], w[0]) and np.array_equal(g[1], w[1])
