@@ -21,7 +21,7 @@ CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(CSRC, "build")
 LIB = os.path.join(HERE, "libkamihip.so")
 ARCH = "gfx950"
-SOURCES = ["kh_api.hip", "encode.hip", "forward_simple.hip"]
+SOURCES = ["kh_api.hip", "encode.hip", "forward_simple.hip", "tower_mfma.hip"]
 HIPCC_FLAGS = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-Wall", "-Wno-unused-result",
                "-ffp-contract=fast"]
 

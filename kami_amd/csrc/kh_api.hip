@@ -98,6 +98,11 @@ struct Weights {
     DevMem simple;                       // fp32 [tap][ci][co] + scale/shift per layer
     std::vector<kh::SimpleLayer> layers; // stem, 2R tower convs, policyconv, policyconv2, valueconv
     const float *fcw = nullptr, *fcb = nullptr;
+    // whole-network MFMA kernel (tower_mfma.hip): packed fragment stream + folded parameters
+    DevMem tw_stream, tw_par, tw_fc4;
+    int tw_nchunks = 0, tw_npar = 0, tw_FP = 0;
+    bool tw_ok = false;
+    std::string tw_why;
 };
 
 // Eval-mode BatchNorm folded to an epilogue (scale, shift):
@@ -109,6 +114,93 @@ void fold_bn(const ConvBN& c, int co, float* scale, float* shift)
         scale[i] = s;
         shift[i] = (c.b[i] - c.rm[i]) * s + c.be[i];
     }
+}
+
+uint16_t f2bf16(float f)
+{
+    uint32_t u;
+    memcpy(&u, &f, 4);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x40);   // keep NaN a NaN
+    u += 0x7fffu + ((u >> 16) & 1u);                                            // round to nearest even
+    return (uint16_t)(u >> 16);
+}
+uint16_t f2f16(float f)
+{
+    _Float16 h = (_Float16)f;
+    uint16_t r;
+    memcpy(&r, &h, 2);
+    return r;
+}
+
+// Append one layer's MFMA A-operand fragments (v_mfma_f32_32x32x16: lane l = (r = l & 31, h = l >> 5)
+// holds W[co = ms*32 + r][k = 8h + j], j = 0..7) in consumption order tap -> k-step -> ms, BN scale
+// folded in before rounding, zero-padded to (MS*32, KS*16) and to a whole number of 8-fragment chunks.
+void pack_layer(std::vector<uint16_t>& out, int dtype, const float* w, const float* scale, int Co, int Ci,
+                int taps, int KS, int MS)
+{
+    for (int tap = 0; tap < taps; ++tap)
+        for (int ks = 0; ks < KS; ++ks)
+            for (int ms = 0; ms < MS; ++ms)
+                for (int l = 0; l < 64; ++l) {
+                    const int r = l & 31, h = l >> 5;
+                    for (int j = 0; j < 8; ++j) {
+                        const int co = ms * 32 + r, ci = ks * 16 + 8 * h + j;
+                        float v = 0.0f;
+                        if (co < Co && ci < Ci) v = w[((size_t)co * Ci + ci) * taps + tap] * (scale ? scale[co] : 1.0f);
+                        out.push_back(dtype == KH_BF16 ? f2bf16(v) : f2f16(v));
+                    }
+                }
+    while (out.size() % 4096) out.push_back(0);
+}
+
+int build_tower(Weights& W, const HostNet& n, int dtype, int F, int C, int R)
+{
+    using namespace kh;
+    if (C > TW_CP) { W.tw_why = "filters > 64 not supported by the MFMA tower kernel yet"; return KH_OK; }
+    if (F > 128) { W.tw_why = "features > 128 not supported by the MFMA tower kernel yet"; return KH_OK; }
+    const int FP = F <= 32 ? 32 : 128;
+    if (tower_lds_bytes(FP, R) > 160 * 1024) { W.tw_why = "too many residual blocks for the LDS parameter area"; return KH_OK; }
+    std::vector<float> sc(128), sh(128);
+    std::vector<uint16_t> stream;
+    std::vector<float> par((size_t)tower_par_copy_floats(R), 0.0f);
+    fold_bn(n.stem, C, sc.data(), sh.data());
+    pack_layer(stream, dtype, n.stem.w, sc.data(), C, F, 9, FP / 16, 2);
+    memcpy(par.data(), sh.data(), sizeof(float) * C);
+    for (int i = 0; i < 2 * R; ++i) {
+        fold_bn(n.res[i], C, sc.data(), sh.data());
+        pack_layer(stream, dtype, n.res[i].w, sc.data(), C, C, 9, TW_CP / 16, 2);
+        memcpy(par.data() + (size_t)(1 + i) * TW_CP, sh.data(), sizeof(float) * C);
+    }
+    float* pshift1 = par.data() + (size_t)(1 + 2 * R) * TW_CP;
+    fold_bn(n.pconv, KH_POLICY_MID, sc.data(), pshift1);
+    pack_layer(stream, dtype, n.pconv.w, sc.data(), KH_POLICY_MID, C, 1, TW_CP / 16, 4);
+    float* pbias2 = pshift1 + KH_POLICY_MID;
+    memcpy(pbias2, n.p2b, sizeof(float) * KH_POLICY_PLANES);
+    pack_layer(stream, dtype, n.p2w, nullptr, KH_POLICY_PLANES, KH_POLICY_MID, 1, KH_POLICY_MID / 16, 3);
+    float* vw = pbias2 + 96;
+    float vs, vsh;
+    fold_bn(n.vconv, 1, &vs, &vsh);
+    for (int i = 0; i < C; ++i) vw[i] = n.vconv.w[i] * vs;
+    vw[TW_CP] = vsh;
+    // valuefc.weight [256][64] -> [k/4][j][4] so that thread j reads coalesced float4
+    std::vector<float> fc4((size_t)KH_VALUE_WIDTH * 64 + KH_VALUE_WIDTH);
+    for (int j = 0; j < KH_VALUE_WIDTH; ++j)
+        for (int k = 0; k < 64; ++k) fc4[((size_t)(k / 4) * KH_VALUE_WIDTH + j) * 4 + (k & 3)] = n.fcw[(size_t)j * 64 + k];
+    memcpy(fc4.data() + (size_t)KH_VALUE_WIDTH * 64, n.fcb, sizeof(float) * KH_VALUE_WIDTH);
+
+    W.tw_nchunks = (int)(stream.size() / 4096);
+    W.tw_npar = (int)par.size();
+    W.tw_FP = FP;
+    int rc = 0;
+    rc |= W.tw_stream.ensure(stream.size() * 2);
+    rc |= W.tw_par.ensure(par.size() * 4);
+    rc |= W.tw_fc4.ensure(fc4.size() * 4);
+    if (rc) return KH_ERR_HIP;
+    HIPCHK(hipMemcpy(W.tw_stream.p, stream.data(), stream.size() * 2, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(W.tw_par.p, par.data(), par.size() * 4, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(W.tw_fc4.p, fc4.data(), fc4.size() * 4, hipMemcpyHostToDevice));
+    W.tw_ok = true;
+    return KH_OK;
 }
 
 int build_simple(Weights& W, const HostNet& n, int F, int C, int R)
@@ -170,6 +262,7 @@ struct Slot {
 
 struct kh_engine {
     kh_config cfg;
+    int num_cus = 256;
     std::mutex wmu;
     std::shared_ptr<Weights> weights;
     std::mutex smu;
@@ -266,12 +359,33 @@ int forward_simple(kh_engine* e, const Weights& W, Slot& s, const float* d_in, i
     return KH_OK;
 }
 
+// The throughput path: one persistent kernel for the whole forward pass (tower_mfma.hip).
+int forward_tower(kh_engine* e, const Weights& W, Slot& s, const float* d_in, int B,
+                  float* d_policy, float* d_vfull, float* d_logits_out)
+{
+    if (!W.tw_ok) return fail(KH_ERR_INVALID, "bf16/f16 path unavailable for this configuration: %s", W.tw_why.c_str());
+    if (reinterpret_cast<uintptr_t>(d_in) & 15) return fail(KH_ERR_INVALID, "input planes must be 16-byte aligned");
+    hipStream_t st = s.stream;
+    int* flags = s.flags.as<int>();
+    HIPCHK(hipMemsetAsync(flags, 0, 16, st));
+    kh::TowerArgs a;
+    a.in = d_in; a.B = B; a.F = e->cfg.features; a.R = e->cfg.residuals;
+    a.wstream = W.tw_stream.as<char>(); a.nchunks = W.tw_nchunks;
+    a.params = W.tw_par.as<float>(); a.npar = W.tw_npar;
+    a.fcw4 = W.tw_fc4.as<float>(); a.fcb = W.tw_fc4.as<float>() + (size_t)KH_VALUE_WIDTH * 64;
+    a.policy = d_policy; a.vfull = d_vfull; a.logits = d_logits_out; a.flags = flags;
+    HIPCHK(kh::launch_tower(e->cfg.dtype, W.tw_FP, a, e->num_cus, st));
+    return KH_OK;
+}
+
 int forward_dispatch(kh_engine* e, const Weights& W, Slot& s, const float* d_in, int B,
                      float* d_policy, float* d_vfull, float* d_logits_out)
 {
     switch (e->cfg.dtype) {
     case KH_F32: return forward_simple(e, W, s, d_in, B, d_policy, d_vfull, d_logits_out);
-    default: return fail(KH_ERR_INVALID, "dtype %d not built into this library", e->cfg.dtype);
+    case KH_BF16:
+    case KH_F16: return forward_tower(e, W, s, d_in, B, d_policy, d_vfull, d_logits_out);
+    default: return fail(KH_ERR_INVALID, "bad dtype %d", e->cfg.dtype);
     }
 }
 
@@ -382,6 +496,7 @@ int kh_create(const kh_config* cfg, kh_engine** out)
                     cfg->device, prop.gcnArchName);
     kh_engine* e = new kh_engine();
     e->cfg = *cfg;
+    e->num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     *out = e;
     return KH_OK;
 }
@@ -409,7 +524,11 @@ int kh_load_weights(kh_engine* e, const float* blob, size_t nfloats, int generat
     W->generation = generation;
     W->blob.assign(blob, blob + nfloats);
     HostNet n = parse_blob(W->blob.data(), F, C, R);
-    if ((rc = build_simple(*W, n, F, C, R))) return rc;
+    if (e->cfg.dtype == KH_F32) {
+        if ((rc = build_simple(*W, n, F, C, R))) return rc;
+    } else {
+        if ((rc = build_tower(*W, n, e->cfg.dtype, F, C, R))) return rc;
+    }
     std::lock_guard<std::mutex> lk(e->wmu);
     e->weights = W;                  // calls in flight keep their own reference
     return KH_OK;

@@ -32,4 +32,30 @@ void launch_softmax4672(const float* logits, float* policy, int B, int* flags, h
 void launch_value_fc(const float* v64, const float* fcw, const float* fcb, float* value_full,
                      int B, int* flags, hipStream_t s);
 
+// ---- tower_mfma.hip ---------------------------------------------------------------------
+// Whole-network persistent MFMA kernel (bf16 / f16 operands, fp32 accumulate).
+constexpr int TW_NB = 2;     // boards per workgroup pass
+constexpr int TW_CP = 64;    // channel count the kernel is specialised for (smaller nets are zero-padded)
+
+struct TowerArgs {
+    const float* in;         // [B][8][8][F] fp32 planes
+    int B, F, R;
+    const char* wstream;     // packed weight fragments, nchunks x 8 KB (see pack_tower in kh_api.hip)
+    int nchunks;
+    const float* params;     // folded shifts / value-conv weights, npar floats
+    int npar;
+    const float* fcw4;       // valuefc.weight re-laid [k/4][j][4]
+    const float* fcb;        // [256]
+    float* policy;           // [B][4672]
+    float* vfull;            // [B][256]
+    float* logits;           // nullable [B][4672]
+    int* flags;              // [0] policy NaN, [1] value NaN
+};
+
+// floats of LDS parameter area: shifts of the 1+2R 3x3 layers, policy shifts/bias, value conv, scratch
+__host__ __device__ constexpr int tower_par_copy_floats(int R) { return (1 + 2 * R) * TW_CP + 128 + 96 + TW_CP + 4; }
+__host__ __device__ constexpr int tower_par_floats(int R) { return tower_par_copy_floats(R) + TW_NB * 64 + 16; }
+int tower_lds_bytes(int FP, int R);
+hipError_t launch_tower(int dtype, int FP, const TowerArgs& a, int num_cus, hipStream_t s);
+
 }  // namespace kh

@@ -1,0 +1,480 @@
+// tower_mfma.hip — the throughput path: the WHOLE network forward (kami/nn/nn.cpp:59-91) as ONE
+// persistent gfx950 kernel.  bf16 or f16 operands, fp32 accumulation on the matrix cores
+// (v_mfma_f32_32x32x16_{bf16,f16}).
+//
+// Why one kernel: at batch 512 the 6x64 net is only ~35 GFLOP — ~14 us at the MFMA peak — so a
+// launch per layer (13 conv layers + heads, ~1.5 us per dependent boundary) would cost more than
+// the arithmetic.  Instead one workgroup owns TW_NB boards for the whole forward pass:
+//
+//   HBM  --fp32 planes-->  LDS S (bf16, 10x12 zero-haloed pixel grid per board)
+//   stem 3x3 conv S -> X, then per residual block  X -conv1-> T,  T -conv2(+X)-> X   (all in LDS)
+//   heads: value 1x1 + FC + tanh (VALU), policy 1x1 -> P, policy 1x1 -> logits L, softmax -> HBM
+//
+// Activations never leave the CU.  Each 3x3 conv is an implicit GEMM  D[co][pixel] =
+// sum_k W[co][k] * X[k][pixel], k = (tap, ci):  weights are the MFMA A operand, pre-packed on the
+// host in exact fragment order; activations are the B operand, read straight from the pixel-major
+// LDS image (one ds_read_b128 per lane per 16-channel k-step, tap shifts are immediates).  Output
+// channels land 4-consecutive per lane, so the epilogue (ReLU, +skip, convert) writes 8-byte
+// packed groups back to LDS.  BatchNorm (eval) is folded: scale into the weights before rounding,
+// shift into the accumulator's initial value.
+//
+// Weights (~1 MB for 6x64, L2 resident) stream through a 6-slot LDS ring of 8 KB chunks by
+// LDS-DMA (global_load_lds_dwordx4), one workgroup barrier per chunk, prefetched 5 chunks ahead
+// behind a counted s_waitcnt vmcnt; the stream is cyclic over the layers so the prefetch runs
+// across layer and board-group boundaries.
+//
+// LDS bank conflicts: pixel stride = 2*C + 16 bytes and row pitch 12, with the lane->pixel map
+// PIXMAP chosen so that every 16-lane group of a ds_read_b128 touches 16 distinct 16-byte slots
+// for every tap (MI355X_MICROARCH.md §LDS: groups {0-3,12-15,20-27}, {4-11,16-19,28-31}).
+#include "kh_internal.h"
+
+namespace kh {
+
+using bf16x8 = __attribute__((ext_vector_type(8))) __bf16;
+using f16x8 = __attribute__((ext_vector_type(8))) _Float16;
+using f32x16 = __attribute__((ext_vector_type(16))) float;
+using u32x4 = __attribute__((ext_vector_type(4))) unsigned;
+using u32x2 = __attribute__((ext_vector_type(2))) unsigned;
+
+// ---------------------------------------------------------------- geometry (bytes unless noted)
+constexpr int PITCH = 12;                       // pixels per padded row (8 + halo, padded for banking)
+constexpr int NPIX = 10 * PITCH;                // padded pixels per board
+constexpr int XSTR = TW_CP * 2 + 16;            // 144: pixel stride of the C-channel images
+constexpr int XBOARD = NPIX * XSTR;             // 17 280
+constexpr int PSTR = KH_POLICY_MID * 2 + 16;    // 272: pixel stride of the policy mid image
+constexpr int PBOARD = 64 * PSTR;               // dense 64 pixels (1x1 conv needs no halo)
+constexpr int LBOARD = KH_PSIZE * 4;            // logits fp32 per board
+constexpr int RING_D = 6;
+constexpr int CHUNK = 8192;                     // 8 fragments of 1 KB
+// The DMA ring sits at LDS offset 0 so that its addresses fit M0's 16-bit LDS offset field.
+constexpr int LDS_RING = 0;
+constexpr int LDS_X = RING_D * CHUNK;           // 49 152
+constexpr int LDS_ST = LDS_X + TW_NB * XBOARD;  // 83 712
+constexpr int ST_MIN = TW_NB * LBOARD - TW_NB * XBOARD + TW_NB * PBOARD;   // L spills past X, P at the end
+
+__host__ __device__ constexpr int st_size(int FP)
+{
+    int s = TW_NB * NPIX * (FP * 2 + 16);
+    return s > ST_MIN ? s : ST_MIN;
+}
+
+// lane column r (0..31) of a 32-pixel MFMA tile -> local pixel (row 0..3)*8 + x.  Hardware lane
+// groups {0-3,12-15,20-27} take rows 0 and 2, {4-11,16-19,28-31} rows 1 and 3: with PITCH 12 the
+// padded pixel indices of each group are distinct mod 16.
+__device__ __constant__ const unsigned char PIXMAP[32] = {
+    0, 1, 2, 3,                 /* lanes 0-3   : row 0, x 0-3 */
+    8, 9, 10, 11, 12, 13, 14, 15,   /* lanes 4-11  : row 1, x 0-7 */
+    4, 5, 6, 7,                 /* lanes 12-15 : row 0, x 4-7 */
+    24, 25, 26, 27,             /* lanes 16-19 : row 3, x 0-3 */
+    16, 17, 18, 19, 20, 21, 22, 23, /* lanes 20-27 : row 2, x 0-7 */
+    28, 29, 30, 31              /* lanes 28-31 : row 3, x 4-7 */
+};
+
+template <typename T> struct Elem;
+template <> struct Elem<__bf16> {
+    using vec8 = bf16x8;
+    static __device__ __forceinline__ f32x16 mfma(vec8 a, vec8 b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0); }
+};
+template <> struct Elem<_Float16> {
+    using vec8 = f16x8;
+    static __device__ __forceinline__ f32x16 mfma(vec8 a, vec8 b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0); }
+};
+
+template <typename T> __device__ __forceinline__ unsigned pack2(float lo, float hi)
+{
+    T a = (T)lo, b = (T)hi;
+    return (unsigned)__builtin_bit_cast(unsigned short, a) | ((unsigned)__builtin_bit_cast(unsigned short, b) << 16);
+}
+template <typename T> __device__ __forceinline__ float unpack_lo(unsigned u) { return (float)__builtin_bit_cast(T, (unsigned short)(u & 0xffffu)); }
+template <typename T> __device__ __forceinline__ float unpack_hi(unsigned u) { return (float)__builtin_bit_cast(T, (unsigned short)(u >> 16)); }
+
+__device__ __forceinline__ float relu_nan(float v) { return v < 0.0f ? 0.0f : v; }   // NaN propagates (torch::relu)
+
+// ---------------------------------------------------------------- weight stream (LDS-DMA ring)
+struct Pipe {
+    const char* stream;     // packed fragments, nch chunks of 8 KB, cyclic
+    int nch;
+    int next;               // chunk index to issue next
+    int islot, cslot;       // ring slots: next to fill / next to consume
+    unsigned ring;          // LDS byte offset of the ring
+};
+
+__device__ __forceinline__ void glds16(const char* gsrc, unsigned lds_dst)
+{
+    // LDS-DMA: 64 lanes x 16 B -> LDS[M0 + lane*16].  M0 is written in the same statement that
+    // reads it and restored (cdna_hip_programming.md §5.7).
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
+}
+
+__device__ __forceinline__ void pipe_issue(Pipe& p, int wave, int lane)
+{
+    const char* src = p.stream + (size_t)p.next * CHUNK + wave * 2048 + lane * 16;
+    const unsigned dst = p.ring + p.islot * CHUNK + wave * 2048;
+    glds16(src, dst);
+    glds16(src + 1024, dst + 1024);
+    p.next = (p.next + 1 == p.nch) ? 0 : p.next + 1;
+    p.islot = (p.islot + 1 == RING_D) ? 0 : p.islot + 1;
+}
+
+// Make the next chunk readable by every wave and refill the slot that was just retired.
+// Before the wait RING_D-1 chunks are outstanding per wave (2 DMA ops each); the oldest is the
+// one wanted, so all but the 2*(RING_D-2) youngest ops must have landed.
+__device__ __forceinline__ unsigned pipe_consume(Pipe& p, int wave, int lane)
+{
+    asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(2 * (RING_D - 2)) : "memory");
+    pipe_issue(p, wave, lane);
+    const unsigned off = p.ring + p.cslot * CHUNK;
+    p.cslot = (p.cslot + 1 == RING_D) ? 0 : p.cslot + 1;
+    return off;
+}
+
+__device__ __forceinline__ void lds_barrier()
+{
+    // all of this wave's LDS writes complete, then rendezvous (no vmcnt: DMA stays in flight)
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
+// ---------------------------------------------------------------- implicit-GEMM layer
+// D[ms] (32 channels x 32 pixels each) += W-fragments (ring) x activation fragments (LDS image).
+// b_base: this lane's byte offset of pixel (y-1, x-1) of its column's pixel, chunk h;  TAPS = 9
+// walks the 3x3 window (dy*PITCH + dx) * stride, TAPS = 1 stays put.  KS 16-channel k-steps per tap.
+template <typename T, int TAPS, int KS, int MS>
+__device__ __forceinline__ void gemm_layer(Pipe& p, const char* smem, int wave, int lane,
+                                           unsigned b_base, int stride, f32x16 (&acc)[MS])
+{
+    using V = typename Elem<T>::vec8;
+    int f = 0;
+    unsigned a_off = 0;
+#pragma unroll
+    for (int tap = 0; tap < TAPS; ++tap) {
+        const unsigned toff = (TAPS == 9) ? (unsigned)(((tap / 3) * PITCH + (tap % 3)) * stride) : 0u;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            const V b = *reinterpret_cast<const V*>(smem + b_base + toff + ks * 32);
+#pragma unroll
+            for (int ms = 0; ms < MS; ++ms) {
+                if ((f & 7) == 0) a_off = pipe_consume(p, wave, lane) + lane * 16;
+                const V a = *reinterpret_cast<const V*>(smem + a_off + (f & 7) * 1024);
+                acc[ms] = Elem<T>::mfma(a, b, acc[ms]);
+                ++f;
+            }
+        }
+    }
+}
+
+// accumulator initial value = folded BatchNorm shift of this lane's channels
+template <int MS>
+__device__ __forceinline__ void acc_init(f32x16 (&acc)[MS], const float* shift, int h)
+{
+#pragma unroll
+    for (int ms = 0; ms < MS; ++ms)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const float4 s = *reinterpret_cast<const float4*>(shift + ms * 32 + 8 * g + 4 * h);
+            acc[ms][4 * g + 0] = s.x; acc[ms][4 * g + 1] = s.y; acc[ms][4 * g + 2] = s.z; acc[ms][4 * g + 3] = s.w;
+        }
+}
+
+// ReLU (+ skip added after it, nn.cpp:31), convert, 8-byte packed stores to the output image.
+template <typename T, int MS, bool SKIP>
+__device__ __forceinline__ void conv_epilogue(const f32x16 (&acc)[MS], char* smem, unsigned out_pix, int h)
+{
+#pragma unroll
+    for (int ms = 0; ms < MS; ++ms)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const unsigned addr = out_pix + (ms * 32 + 8 * g + 4 * h) * 2;
+            float v0 = relu_nan(acc[ms][4 * g + 0]), v1 = relu_nan(acc[ms][4 * g + 1]);
+            float v2 = relu_nan(acc[ms][4 * g + 2]), v3 = relu_nan(acc[ms][4 * g + 3]);
+            if (SKIP) {
+                const u32x2 old = *reinterpret_cast<const u32x2*>(smem + addr);
+                v0 += unpack_lo<T>(old.x); v1 += unpack_hi<T>(old.x);
+                v2 += unpack_lo<T>(old.y); v3 += unpack_hi<T>(old.y);
+            }
+            u32x2 o;
+            o.x = pack2<T>(v0, v1);
+            o.y = pack2<T>(v2, v3);
+            *reinterpret_cast<u32x2*>(smem + addr) = o;
+        }
+}
+
+__device__ __forceinline__ float wave_max_f(float v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+__device__ __forceinline__ float wave_sum_f(float v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+// ---------------------------------------------------------------- the kernel
+// KS_STEM = padded input planes / 16 (2 for F <= 32, 8 for F <= 128).
+template <typename T, int KS_STEM>
+__global__ __launch_bounds__(256, 1) void tower_kernel(TowerArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int FP = KS_STEM * 16;
+    constexpr int SSTR = FP * 2 + 16;
+    constexpr int SBOARD = NPIX * SSTR;
+    constexpr int ST_SIZE = st_size(FP);
+    constexpr int LDS_PAR = LDS_ST + ST_SIZE;
+    constexpr int LDS_P = LDS_ST + ST_SIZE - TW_NB * PBOARD;
+    constexpr int LDS_L = LDS_X;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int h = lane >> 5;
+    const int R = a.R, F = a.F;
+
+    // parameter block -> LDS (plain loads, before any DMA is in flight)
+    float* par = reinterpret_cast<float*>(smem + LDS_PAR);
+    for (int i = tid; i < a.npar; i += 256) par[i] = a.params[i];
+    const float* shift3 = par;                              // [(1 + 2R)][64]
+    const float* pshift1 = par + (1 + 2 * R) * TW_CP;       // [128]
+    const float* pbias2 = pshift1 + KH_POLICY_MID;          // [96]
+    const float* vw = pbias2 + 96;                          // [64] valueconv weight * bn scale
+    const float* vsh = vw + TW_CP;                          // [4]  folded valueconv/bn shift
+    float* v64 = const_cast<float*>(vsh) + 4;               // [TW_NB][64] scratch
+    float* red = v64 + TW_NB * 64;                          // [16] reduction scratch
+
+    // this wave's 32-pixel column tile: board wave>>1, rows 4*(wave&1)..+3
+    const int wb = wave >> 1;
+    const int lp = PIXMAP[lane & 31];
+    const int py = 4 * (wave & 1) + (lp >> 3), px = lp & 7;
+    const unsigned xin = LDS_X + wb * XBOARD + (py * PITCH + px) * XSTR + h * 16;       // tap (0,0) = pixel (y-1,x-1)
+    const unsigned tin = LDS_ST + wb * XBOARD + (py * PITCH + px) * XSTR + h * 16;
+    const unsigned sin = LDS_ST + wb * SBOARD + (py * PITCH + px) * SSTR + h * 16;
+    const unsigned xout = LDS_X + wb * XBOARD + ((py + 1) * PITCH + px + 1) * XSTR;     // own pixel
+    const unsigned tout = LDS_ST + wb * XBOARD + ((py + 1) * PITCH + px + 1) * XSTR;
+    const unsigned pout = LDS_P + wb * PBOARD + (py * 8 + px) * PSTR;
+    const unsigned pin = pout + h * 16;
+
+    Pipe pipe;
+    pipe.stream = a.wstream; pipe.nch = a.nchunks; pipe.next = 0; pipe.islot = 0; pipe.cslot = 0;
+    pipe.ring = LDS_RING;
+    __syncthreads();                       // params visible; nothing in flight yet
+#pragma unroll
+    for (int i = 0; i < RING_D - 1; ++i) pipe_issue(pipe, wave, lane);
+
+    const int ngroups = (a.B + TW_NB - 1) / TW_NB;
+    for (int grp = blockIdx.x; grp < ngroups; grp += gridDim.x) {
+        const int b0 = grp * TW_NB;
+
+        // ---- 1. zero X and S (halos, padded channels), then planes fp32 -> T into S interior
+        {
+            const u32x4 z = { 0, 0, 0, 0 };
+            for (int i = tid; i < (LDS_ST - LDS_X + TW_NB * SBOARD) / 16; i += 256)
+                *reinterpret_cast<u32x4*>(smem + LDS_X + i * 16) = z;
+            lds_barrier();
+            const float invF = 1.0f / (float)F;
+            const int nflt = 64 * F;                       // floats per board
+            for (int bb = 0; bb < TW_NB; ++bb) {
+                if (b0 + bb >= a.B) break;
+                const float* src = a.in + (size_t)(b0 + bb) * nflt;
+                char* sb = smem + LDS_ST + bb * SBOARD;
+                for (int q = tid; q * 4 < nflt; q += 256) {
+                    const int e = q * 4;
+                    const float4 v = *reinterpret_cast<const float4*>(src + e);   // nflt % 4 == 0, base 16-B aligned
+                    int p = (int)(((float)e + 0.5f) * invF);
+                    int c = e - p * F;
+                    const float vv[4] = { v.x, v.y, v.z, v.w };
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const T t = (T)vv[j];
+                        *reinterpret_cast<unsigned short*>(sb + (((p >> 3) + 1) * PITCH + (p & 7) + 1) * SSTR + c * 2) =
+                            __builtin_bit_cast(unsigned short, t);
+                        if (++c == F) { c = 0; ++p; }
+                    }
+                }
+            }
+            lds_barrier();
+        }
+
+        // ---- 2. stem: conv1 + batchnorm1 + relu, S -> X                       nn.cpp:62-65
+        {
+            f32x16 acc[2];
+            acc_init<2>(acc, shift3, h);
+            gemm_layer<T, 9, KS_STEM, 2>(pipe, smem, wave, lane, sin, SSTR, acc);
+            conv_epilogue<T, 2, false>(acc, smem, xout, h);
+            lds_barrier();
+            // T shares LDS with S: clear T's halo before the tower reads through it
+            const u32x4 z = { 0, 0, 0, 0 };
+            for (int i = tid; i < TW_NB * NPIX; i += 256) {
+                const int pp = i % NPIX, yy = pp / PITCH, xx = pp % PITCH;
+                if (yy >= 1 && yy <= 8 && xx >= 1 && xx <= 8) continue;
+                char* d = smem + LDS_ST + (i / NPIX) * XBOARD + pp * XSTR;
+#pragma unroll
+                for (int k = 0; k < XSTR / 16; ++k) *reinterpret_cast<u32x4*>(d + k * 16) = z;
+            }
+        }
+
+        // ---- 3. residual tower: x = x + relu(bn2(conv2(relu(bn1(conv1 x)))))   nn.cpp:26-34
+        for (int r = 0; r < R; ++r) {
+            f32x16 acc[2];
+            acc_init<2>(acc, shift3 + (1 + 2 * r) * TW_CP, h);
+            gemm_layer<T, 9, TW_CP / 16, 2>(pipe, smem, wave, lane, xin, XSTR, acc);
+            conv_epilogue<T, 2, false>(acc, smem, tout, h);
+            lds_barrier();
+            acc_init<2>(acc, shift3 + (2 + 2 * r) * TW_CP, h);
+            gemm_layer<T, 9, TW_CP / 16, 2>(pipe, smem, wave, lane, tin, XSTR, acc);
+            conv_epilogue<T, 2, true>(acc, smem, xout, h);
+            lds_barrier();
+        }
+
+        // ---- 4a. value head, first half: valueconv + vbatchnorm + relu          nn.cpp:83-85
+        if (tid < TW_NB * 64) {
+            const int bb = tid >> 6, p = tid & 63;
+            const char* xp = smem + LDS_X + bb * XBOARD + (((p >> 3) + 1) * PITCH + (p & 7) + 1) * XSTR;
+            float s = 0.0f;
+#pragma unroll
+            for (int k = 0; k < TW_CP / 8; ++k) {
+                const u32x4 u = *reinterpret_cast<const u32x4*>(xp + k * 16);
+                const float* w = vw + k * 8;
+                s = fmaf(unpack_lo<T>(u.x), w[0], s); s = fmaf(unpack_hi<T>(u.x), w[1], s);
+                s = fmaf(unpack_lo<T>(u.y), w[2], s); s = fmaf(unpack_hi<T>(u.y), w[3], s);
+                s = fmaf(unpack_lo<T>(u.z), w[4], s); s = fmaf(unpack_hi<T>(u.z), w[5], s);
+                s = fmaf(unpack_lo<T>(u.w), w[6], s); s = fmaf(unpack_hi<T>(u.w), w[7], s);
+            }
+            v64[bb * 64 + p] = relu_nan(s + vsh[0]);
+        }
+
+        // ---- 4b. policy head: policyconv + pbatchnorm + relu, X -> P (128 ch)   nn.cpp:72-74
+        {
+            f32x16 acc[4];
+            acc_init<4>(acc, pshift1, h);
+            gemm_layer<T, 1, TW_CP / 16, 4>(pipe, smem, wave, lane, xin + (PITCH + 1) * XSTR, XSTR, acc);
+            conv_epilogue<T, 4, false>(acc, smem, pout, h);
+            lds_barrier();
+        }
+
+        // ---- 4c. policyconv2 (+bias): P -> logits L[board][pixel*73 + plane]    nn.cpp:75-79
+        {
+            f32x16 acc[3];
+            acc_init<3>(acc, pbias2, h);
+            gemm_layer<T, 1, KH_POLICY_MID / 16, 3>(pipe, smem, wave, lane, pin, PSTR, acc);
+            float* lrow = reinterpret_cast<float*>(smem + LDS_L + wb * LBOARD) + (py * 8 + px) * KH_POLICY_PLANES;
+#pragma unroll
+            for (int ms = 0; ms < 3; ++ms)
+#pragma unroll
+                for (int g = 0; g < 4; ++g)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const int plane = ms * 32 + 8 * g + 4 * h + i;
+                        if (plane < KH_POLICY_PLANES) lrow[plane] = acc[ms][4 * g + i];
+                    }
+            lds_barrier();
+        }
+
+        // ---- 4d. softmax over all 4672 logits of a board (nn.cpp:80); 128 threads per board
+        {
+            const int bb = tid >> 7, tt = tid & 127;
+            const bool live = (b0 + bb) < a.B;
+            const float4* L4 = reinterpret_cast<const float4*>(smem + LDS_L + bb * LBOARD);
+            constexpr int NQ = KH_PSIZE / 4;               // 1168 float4
+            if (a.logits && live) {
+                float4* lo = reinterpret_cast<float4*>(a.logits + (size_t)(b0 + bb) * KH_PSIZE);
+                for (int q = tt; q < NQ; q += 128) lo[q] = L4[q];
+            }
+            float m = -INFINITY;
+            for (int q = tt; q < NQ; q += 128) {
+                const float4 v = L4[q];
+                m = fmaxf(fmaxf(m, fmaxf(v.x, v.y)), fmaxf(v.z, v.w));
+            }
+            m = wave_max_f(m);
+            if (lane == 0) red[wave] = m;
+            lds_barrier();
+            m = fmaxf(red[bb * 2], red[bb * 2 + 1]);
+            float s = 0.0f;
+            for (int q = tt; q < NQ; q += 128) {
+                const float4 v = L4[q];
+                s += (__expf(v.x - m) + __expf(v.y - m)) + (__expf(v.z - m) + __expf(v.w - m));
+            }
+            s = wave_sum_f(s);
+            if (lane == 0) red[4 + wave] = s;
+            lds_barrier();
+            s = red[4 + bb * 2] + red[4 + bb * 2 + 1];
+            const float ls = __logf(s);
+            bool nan = false;
+            if (live) {
+                float4* po = reinterpret_cast<float4*>(a.policy + (size_t)(b0 + bb) * KH_PSIZE);
+                for (int q = tt; q < NQ; q += 128) {
+                    const float4 v = L4[q];
+                    float4 o;
+                    o.x = __expf((v.x - m) - ls); o.y = __expf((v.y - m) - ls);
+                    o.z = __expf((v.z - m) - ls); o.w = __expf((v.w - m) - ls);
+                    nan |= (o.x != o.x) | (o.y != o.y) | (o.z != o.z) | (o.w != o.w);
+                    po[q] = o;
+                }
+            }
+            if (__any(nan) && lane == 0) atomicOr(&a.flags[0], 1);
+        }
+
+        // ---- 4e. value head, second half: valuefc + tanh -> [B][256]            nn.cpp:86-88
+        {
+            const float4* w4 = reinterpret_cast<const float4*>(a.fcw4) + tid;
+            float s[TW_NB];
+#pragma unroll
+            for (int bb = 0; bb < TW_NB; ++bb) s[bb] = 0.0f;
+#pragma unroll 4
+            for (int k = 0; k < 16; ++k) {
+                const float4 w = w4[k * KH_VALUE_WIDTH];
+#pragma unroll
+                for (int bb = 0; bb < TW_NB; ++bb) {
+                    const float* v = v64 + bb * 64 + k * 4;
+                    s[bb] = fmaf(v[0], w.x, s[bb]); s[bb] = fmaf(v[1], w.y, s[bb]);
+                    s[bb] = fmaf(v[2], w.z, s[bb]); s[bb] = fmaf(v[3], w.w, s[bb]);
+                }
+            }
+            const float bias = a.fcb[tid];
+            bool nan = false;
+#pragma unroll
+            for (int bb = 0; bb < TW_NB; ++bb) {
+                if (b0 + bb < a.B) {
+                    const float r = tanhf(s[bb] + bias);
+                    nan |= (r != r);
+                    a.vfull[(size_t)(b0 + bb) * KH_VALUE_WIDTH + tid] = r;
+                }
+            }
+            if (__any(nan) && lane == 0) atomicOr(&a.flags[1], 1);
+        }
+        lds_barrier();      // L / v64 are dead; the next group may overwrite them
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // drain the prefetch ring before exit
+}
+
+template <typename T, int KS_STEM> static hipError_t launch(const TowerArgs& a, int grid, hipStream_t s)
+{
+    constexpr int FP = KS_STEM * 16;
+    const int lds = LDS_ST + st_size(FP) + tower_par_floats(a.R) * 4;
+    static bool attr_done = false;
+    if (!attr_done) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&tower_kernel<T, KS_STEM>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) return e;
+        attr_done = true;
+    }
+    hipLaunchKernelGGL((tower_kernel<T, KS_STEM>), dim3(grid), dim3(256), lds, s, a);
+    return hipGetLastError();
+}
+
+int tower_lds_bytes(int FP, int R)
+{
+    return LDS_ST + st_size(FP) + tower_par_floats(R) * 4;
+}
+
+hipError_t launch_tower(int dtype, int FP, const TowerArgs& a, int num_cus, hipStream_t s)
+{
+    const int ngroups = (a.B + TW_NB - 1) / TW_NB;
+    const int grid = ngroups < num_cus ? ngroups : num_cus;      // one workgroup per CU (LDS-bound residency)
+    if (dtype == KH_BF16) return FP == 32 ? launch<__bf16, 2>(a, grid, s) : launch<__bf16, 8>(a, grid, s);
+    return FP == 32 ? launch<_Float16, 2>(a, grid, s) : launch<_Float16, 8>(a, grid, s);
+}
+
+}  // namespace kh

@@ -87,6 +87,68 @@ def test_forward_f32_vs_reference_fixtures(net_fixture):
     check_forward(nn, net_fixture, "f32")
 
 
+@pytest.mark.parametrize("dtype", ["f16", "bf16"])
+def test_forward_mfma_vs_reference_fixtures(net_fixture, dtype):
+    """The whole-network MFMA kernel (bf16 / f16 operands, fp32 accumulate) vs the reference's
+    fp32 outputs, within the stated per-dtype tolerance (TOL)."""
+    nn = make_nn(net_fixture, dtype)
+    check_forward(nn, net_fixture, dtype)
+
+
+@pytest.mark.parametrize("dtype", ["f16", "bf16"])
+@pytest.mark.parametrize("F,C,R,B", [(119, 64, 6, 64), (30, 64, 6, 33), (30, 24, 1, 7), (119, 64, 0, 3)])
+def test_forward_mfma_vs_oracle(dtype, F, C, R, B):
+    blob = W.random_weights(F, C, R, seed=F + C + R, peaky=20.0)
+    x = np.random.default_rng(B).random((B, 8, 8, F), dtype=np.float32)
+    nn = NN(8, 8, F, 4672, filters=C, residuals=R, dtype=dtype)
+    nn.load_weights(blob, 1)
+    p, vf, lg = nn.infer_full(x)
+    op, ovf, olg = ko.forward(blob, F, C, R, x)
+    tol = TOL[dtype]
+    np.testing.assert_allclose(lg, olg, atol=tol["logp"], rtol=0)
+    np.testing.assert_allclose(np.log(p), np.log(op), atol=tol["logp"], rtol=0)
+    np.testing.assert_allclose(vf, ovf, atol=tol["value"], rtol=0)
+    assert np.allclose(p.sum(1), 1.0, atol=1e-3)
+
+
+@pytest.mark.parametrize("dtype", ["bf16"])
+def test_mfma_batch_sizes_and_row_independence(dtype):
+    F, C, R = 30, 64, 2
+    blob = W.random_weights(F, C, R, seed=2, peaky=10.0)
+    nn = NN(8, 8, F, 4672, filters=C, residuals=R, dtype=dtype)
+    nn.load_weights(blob, 1)
+    x = np.random.default_rng(0).random((1027, 8, 8, F), dtype=np.float32)
+    p_all, vf_all, _ = nn.infer_full(x, want_logits=False)
+    for b in (1, 2, 63, 513):
+        p, vf, _ = nn.infer_full(x[:b], want_logits=False)
+        assert np.array_equal(p, p_all[:b]) and np.array_equal(vf, vf_all[:b])
+    # determinism: same call twice is bit-identical
+    p2, vf2, _ = nn.infer_full(x, want_logits=False)
+    assert np.array_equal(p2, p_all) and np.array_equal(vf2, vf_all)
+
+
+def test_mfma_nan_guard():
+    F, C, R = 30, 64, 1
+    nn = NN(8, 8, F, 4672, filters=C, residuals=R, dtype="bf16")
+    blob = W.random_weights(F, C, R, seed=3)
+    nn.load_weights(blob, 1)
+    x = np.random.default_rng(0).random((3, 8, 8, F), dtype=np.float32)
+    nn.infer(x)
+    xb = x.copy()
+    xb[2, 3, 3, 1] = np.nan
+    with pytest.raises(KamiError) as ei:
+        nn.infer(xb)
+    assert ei.value.status == L.KH_ERR_NAN_POLICY
+
+
+def test_mfma_unsupported_config_fails_loudly():
+    nn = NN(8, 8, 30, 4672, filters=128, residuals=1, dtype="bf16")
+    nn.load_weights(W.random_weights(30, 128, 1, seed=1), 1)
+    with pytest.raises(KamiError) as ei:
+        nn.infer(np.zeros((1, 8, 8, 30), np.float32))
+    assert ei.value.status == L.KH_ERR_INVALID
+
+
 def test_infer_reference_value_copyout(net_fixture):
     """value[i] = flattened [B,256] tensor element i (nn.cpp:186)."""
     d = net_fixture
