@@ -26,7 +26,12 @@ PEAK_TFLOPS = {"bf16": 2500.0, "f16": 2500.0, "f32": 157.3}   # MI355X_MICROARCH
 def cpu_baseline(F, Cc, R, batch):
     """Reference CPU evaluate() on this box's host cores, on a bounded sample (rank 0, N=1)."""
     ref = os.path.join(ROOT, "oracle", "_ref", "kami_ref")
-    cores = os.cpu_count() or 1
+    # the GPU box gives one GPU's job a 16-core share of the host (gpurun), whatever nproc says
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except AttributeError:
+        cores = os.cpu_count() or 1
+    cores = max(1, min(cores, int(os.environ.get("KAMI_CPU_CORES", "16"))))
     iters = 8
     if os.path.exists(ref):
         try:
