@@ -176,8 +176,9 @@ int build_tower(Weights& W, const HostNet& n, int dtype, int F, int C, int R)
     pack_layer(stream, dtype, n.pconv.w, sc.data(), KH_POLICY_MID, C, 1, TW_CP / 16, 4);
     float* pbias2 = pshift1 + KH_POLICY_MID;
     memcpy(pbias2, n.p2b, sizeof(float) * KH_POLICY_PLANES);
-    pack_layer(stream, dtype, n.p2w, nullptr, KH_POLICY_PLANES, KH_POLICY_MID, 1, KH_POLICY_MID / 16, 3);
-    float* vw = pbias2 + 96;
+    pack_layer(stream, dtype, n.p2w, nullptr, KH_POLICY_PLANES, KH_POLICY_MID, 1, KH_POLICY_MID / 16, 4);
+    if (((stream.size() / 4096) & 1) != 0) stream.resize(stream.size() + 4096, 0);   // parity chunk (see gemm_dummy)
+    float* vw = pbias2 + 128;
     float vs, vsh;
     fold_bn(n.vconv, 1, &vs, &vsh);
     for (int i = 0; i < C; ++i) vw[i] = n.vconv.w[i] * vs;
@@ -256,6 +257,7 @@ struct Slot {
     int cap = 0;                 // boards the scratch is sized for
     DevMem in, x, t, u, ph, logits, policy, v64, vfull, flags, boards, planes;
     bool busy = false;
+    bool flags_clean = false;    // device NaN flags known to be zero
 };
 
 }  // namespace
@@ -367,7 +369,10 @@ int forward_tower(kh_engine* e, const Weights& W, Slot& s, const float* d_in, in
     if (reinterpret_cast<uintptr_t>(d_in) & 15) return fail(KH_ERR_INVALID, "input planes must be 16-byte aligned");
     hipStream_t st = s.stream;
     int* flags = s.flags.as<int>();
-    HIPCHK(hipMemsetAsync(flags, 0, 16, st));
+    if (!s.flags_clean) {               // NaN flags are only ever OR-ed by the kernel: clear on demand,
+        HIPCHK(hipMemsetAsync(flags, 0, 16, st));   // not per launch (a memset node costs a launch boundary)
+        s.flags_clean = true;
+    }
     kh::TowerArgs a;
     a.in = d_in; a.B = B; a.F = e->cfg.features; a.R = e->cfg.residuals;
     a.wstream = W.tw_stream.as<char>(); a.nchunks = W.tw_nchunks;
@@ -446,6 +451,7 @@ int infer_host(kh_engine* e, const float* input, const kh_board* boards, int bat
     }
     HIPCHK(hipMemcpyAsync(flags, s.flags.p, 16, hipMemcpyDeviceToHost, st));
     HIPCHK(hipStreamSynchronize(st));
+    if (flags[0] | flags[1]) s.flags_clean = false;
     if (flags[0]) return fail(KH_ERR_NAN_POLICY, "inference policy output contains NaN");   // nn.cpp:176-177
     if (flags[1]) return fail(KH_ERR_NAN_VALUE, "inference value output contains NaN");     // nn.cpp:179-180
     return KH_OK;

@@ -53,7 +53,7 @@ struct TowerArgs {
 };
 
 // floats of LDS parameter area: shifts of the 1+2R 3x3 layers, policy shifts/bias, value conv, scratch
-__host__ __device__ constexpr int tower_par_copy_floats(int R) { return (1 + 2 * R) * TW_CP + 128 + 96 + TW_CP + 4; }
+__host__ __device__ constexpr int tower_par_copy_floats(int R) { return (1 + 2 * R) * TW_CP + 128 + 128 + TW_CP + 4; }
 __host__ __device__ constexpr int tower_par_floats(int R) { return tower_par_copy_floats(R) + TW_NB * 64 + 16; }
 int tower_lds_bytes(int FP, int R);
 hipError_t launch_tower(int dtype, int FP, const TowerArgs& a, int num_cus, hipStream_t s);

@@ -118,16 +118,23 @@ __device__ __forceinline__ void pipe_issue(Pipe& p, int wave, int lane)
     p.islot = (p.islot + 1 == RING_D) ? 0 : p.islot + 1;
 }
 
-// Make the next chunk readable by every wave and refill the slot that was just retired.
-// Before the wait RING_D-1 chunks are outstanding per wave (2 DMA ops each); the oldest is the
-// one wanted, so all but the 2*(RING_D-2) youngest ops must have landed.
-__device__ __forceinline__ unsigned pipe_consume(Pipe& p, int wave, int lane)
+// Ring protocol (D = RING_D slots, chunk c lives in slot c mod D).  Entering step(c) every wave
+// holds chunk c's fragments in registers (prefetched during step c-1), chunk c+1 is the oldest
+// DMA that may still be in flight and chunks c+2 .. c+D-2 are behind it.  step(c):
+//   1. s_waitcnt vmcnt(2*(D-3))  -> this wave's pieces of chunk c+1 have landed
+//   2. s_barrier                 -> everybody's have; everybody has finished the MFMAs of chunk c-1
+//   3. refill slot (c-1) mod D with chunk c+D-1
+// and returns the LDS offset of chunk c+1, which the caller reads into its other register set
+// while the MFMAs of chunk c run.  A chunk is therefore requested D-2 steps before it is needed.
+__device__ __forceinline__ unsigned pipe_step(Pipe& p, int wave, int lane)
 {
-    asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(2 * (RING_D - 2)) : "memory");
+    asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(2 * (RING_D - 3)) : "memory");
+    // Nothing moves across the step boundary: hipcc otherwise hoists the next step's MFMAs up to
+    // their operand loads and the register double-buffering collapses into load->wait->MFMA.
+    __builtin_amdgcn_sched_barrier(0);
     pipe_issue(p, wave, lane);
-    const unsigned off = p.ring + p.cslot * CHUNK;
     p.cslot = (p.cslot + 1 == RING_D) ? 0 : p.cslot + 1;
-    return off;
+    return p.ring + p.cslot * CHUNK;
 }
 
 __device__ __forceinline__ void lds_barrier()
@@ -139,29 +146,71 @@ __device__ __forceinline__ void lds_barrier()
 // ---------------------------------------------------------------- implicit-GEMM layer
 // D[ms] (32 channels x 32 pixels each) += W-fragments (ring) x activation fragments (LDS image).
 // b_base: this lane's byte offset of pixel (y-1, x-1) of its column's pixel, chunk h;  TAPS = 9
-// walks the 3x3 window (dy*PITCH + dx) * stride, TAPS = 1 stays put.  KS 16-channel k-steps per tap.
-template <typename T, int TAPS, int KS, int MS>
+// walks the 3x3 window (dy*PITCH + dx) * stride, TAPS = 1 stays put.  KS 16-channel k-steps per
+// tap, MS 32-channel output tiles.  One 8-fragment chunk = 8/MS k-steps.  A[PAR] holds this
+// layer's first chunk on entry; on exit A[PAR ^ (chunks & 1)] holds the next layer's.
+template <int TAPS, int KS, int MS> struct LayerShape {
+    static constexpr int KPC = 8 / MS;                       // k-steps per chunk
+    static constexpr int TK = TAPS * KS;                     // real k-steps
+    static constexpr int NCH = (TK + KPC - 1) / KPC;         // chunks (the packer zero-pads the tail)
+};
+
+template <int TAPS, int KS>
+__device__ __forceinline__ constexpr unsigned b_offset(int kk, int stride)
+{
+    // k-steps past the real ones multiply zero weights: point them at tap 0 (always in bounds)
+    const int k = kk < TAPS * KS ? kk : 0;
+    const int tap = k / KS, ks = k % KS;
+    return (unsigned)((TAPS == 9 ? ((tap / 3) * PITCH + (tap % 3)) * stride : 0) + ks * 32);
+}
+
+template <typename T, int TAPS, int KS, int MS, int PAR>
 __device__ __forceinline__ void gemm_layer(Pipe& p, const char* smem, int wave, int lane,
-                                           unsigned b_base, int stride, f32x16 (&acc)[MS])
+                                           unsigned b_base, int stride, f32x16 (&acc)[MS],
+                                           typename Elem<T>::vec8 (&A)[2][8])
 {
     using V = typename Elem<T>::vec8;
-    int f = 0;
-    unsigned a_off = 0;
+    using S = LayerShape<TAPS, KS, MS>;
+    constexpr int KPC = S::KPC;
+    V B[2][KPC];
 #pragma unroll
-    for (int tap = 0; tap < TAPS; ++tap) {
-        const unsigned toff = (TAPS == 9) ? (unsigned)(((tap / 3) * PITCH + (tap % 3)) * stride) : 0u;
+    for (int k = 0; k < KPC; ++k)
+        B[PAR][k] = *reinterpret_cast<const V*>(smem + b_base + b_offset<TAPS, KS>(k, stride));
 #pragma unroll
-        for (int ks = 0; ks < KS; ++ks) {
-            const V b = *reinterpret_cast<const V*>(smem + b_base + toff + ks * 32);
+    for (int n = 0; n < S::NCH; ++n) {
+        const int cur = (PAR + n) & 1, nxt = cur ^ 1;
+        const unsigned a_off = pipe_step(p, wave, lane) + lane * 16;
 #pragma unroll
-            for (int ms = 0; ms < MS; ++ms) {
-                if ((f & 7) == 0) a_off = pipe_consume(p, wave, lane) + lane * 16;
-                const V a = *reinterpret_cast<const V*>(smem + a_off + (f & 7) * 1024);
-                acc[ms] = Elem<T>::mfma(a, b, acc[ms]);
-                ++f;
-            }
+        for (int f = 0; f < 8; ++f) A[nxt][f] = *reinterpret_cast<const V*>(smem + a_off + f * 1024);
+        if (n + 1 < S::NCH) {
+#pragma unroll
+            for (int k = 0; k < KPC; ++k)
+                B[nxt][k] = *reinterpret_cast<const V*>(smem + b_base + b_offset<TAPS, KS>((n + 1) * KPC + k, stride));
+        }
+#pragma unroll
+        for (int k = 0; k < KPC; ++k)
+#pragma unroll
+            for (int ms = 0; ms < MS; ++ms) acc[ms] = Elem<T>::mfma(A[cur][k * MS + ms], B[cur][k], acc[ms]);
+        // Pin the interleave: the next chunk's operand reads go out two per MFMA from the top of
+        // the step (hipcc would otherwise sink them to the end, exposing their latency at the
+        // next barrier); 2 ds_read_b128 per 32-cycle MFMA gap is within the LDS issue budget.
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);   // DS read
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // MFMA
         }
     }
+}
+
+// A chunk of zeros in the stream that only flips the register-set parity back to 0.
+template <typename T, int PAR>
+__device__ __forceinline__ void gemm_dummy(Pipe& p, const char* smem, int wave, int lane,
+                                           typename Elem<T>::vec8 (&A)[2][8])
+{
+    using V = typename Elem<T>::vec8;
+    const unsigned a_off = pipe_step(p, wave, lane) + lane * 16;
+#pragma unroll
+    for (int f = 0; f < 8; ++f) A[PAR ^ 1][f] = *reinterpret_cast<const V*>(smem + a_off + f * 1024);
 }
 
 // accumulator initial value = folded BatchNorm shift of this lane's channels
@@ -216,7 +265,7 @@ __device__ __forceinline__ float wave_sum_f(float v)
 // ---------------------------------------------------------------- the kernel
 // KS_STEM = padded input planes / 16 (2 for F <= 32, 8 for F <= 128).
 template <typename T, int KS_STEM>
-__global__ __launch_bounds__(256, 1) void tower_kernel(TowerArgs a)
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void tower_kernel(TowerArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int FP = KS_STEM * 16;
@@ -238,8 +287,8 @@ __global__ __launch_bounds__(256, 1) void tower_kernel(TowerArgs a)
     for (int i = tid; i < a.npar; i += 256) par[i] = a.params[i];
     const float* shift3 = par;                              // [(1 + 2R)][64]
     const float* pshift1 = par + (1 + 2 * R) * TW_CP;       // [128]
-    const float* pbias2 = pshift1 + KH_POLICY_MID;          // [96]
-    const float* vw = pbias2 + 96;                          // [64] valueconv weight * bn scale
+    const float* pbias2 = pshift1 + KH_POLICY_MID;          // [128] (73 real)
+    const float* vw = pbias2 + 128;                         // [64] valueconv weight * bn scale
     const float* vsh = vw + TW_CP;                          // [4]  folded valueconv/bn shift
     float* v64 = const_cast<float*>(vsh) + 4;               // [TW_NB][64] scratch
     float* red = v64 + TW_NB * 64;                          // [16] reduction scratch
@@ -262,6 +311,12 @@ __global__ __launch_bounds__(256, 1) void tower_kernel(TowerArgs a)
     __syncthreads();                       // params visible; nothing in flight yet
 #pragma unroll
     for (int i = 0; i < RING_D - 1; ++i) pipe_issue(pipe, wave, lane);
+    using V = typename Elem<T>::vec8;
+    V A[2][8];                             // two register sets of weight fragments (current / next chunk)
+    asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(2 * (RING_D - 2)) : "memory");   // chunk 0 landed
+#pragma unroll
+    for (int f = 0; f < 8; ++f) A[0][f] = *reinterpret_cast<const V*>(smem + LDS_RING + lane * 16 + f * 1024);
+    constexpr int P1 = LayerShape<9, KS_STEM, 2>::NCH & 1;   // register-set parity after the stem
 
     const int ngroups = (a.B + TW_NB - 1) / TW_NB;
     for (int grp = blockIdx.x; grp < ngroups; grp += gridDim.x) {
@@ -301,7 +356,7 @@ __global__ __launch_bounds__(256, 1) void tower_kernel(TowerArgs a)
         {
             f32x16 acc[2];
             acc_init<2>(acc, shift3, h);
-            gemm_layer<T, 9, KS_STEM, 2>(pipe, smem, wave, lane, sin, SSTR, acc);
+            gemm_layer<T, 9, KS_STEM, 2, 0>(pipe, smem, wave, lane, sin, SSTR, acc, A);
             conv_epilogue<T, 2, false>(acc, smem, xout, h);
             lds_barrier();
             // T shares LDS with S: clear T's halo before the tower reads through it
@@ -319,11 +374,11 @@ __global__ __launch_bounds__(256, 1) void tower_kernel(TowerArgs a)
         for (int r = 0; r < R; ++r) {
             f32x16 acc[2];
             acc_init<2>(acc, shift3 + (1 + 2 * r) * TW_CP, h);
-            gemm_layer<T, 9, TW_CP / 16, 2>(pipe, smem, wave, lane, xin, XSTR, acc);
+            gemm_layer<T, 9, TW_CP / 16, 2, P1>(pipe, smem, wave, lane, xin, XSTR, acc, A);
             conv_epilogue<T, 2, false>(acc, smem, tout, h);
             lds_barrier();
             acc_init<2>(acc, shift3 + (2 + 2 * r) * TW_CP, h);
-            gemm_layer<T, 9, TW_CP / 16, 2>(pipe, smem, wave, lane, tin, XSTR, acc);
+            gemm_layer<T, 9, TW_CP / 16, 2, P1 ^ 1>(pipe, smem, wave, lane, tin, XSTR, acc, A);
             conv_epilogue<T, 2, true>(acc, smem, xout, h);
             lds_barrier();
         }
@@ -349,19 +404,20 @@ __global__ __launch_bounds__(256, 1) void tower_kernel(TowerArgs a)
         {
             f32x16 acc[4];
             acc_init<4>(acc, pshift1, h);
-            gemm_layer<T, 1, TW_CP / 16, 4>(pipe, smem, wave, lane, xin + (PITCH + 1) * XSTR, XSTR, acc);
+            gemm_layer<T, 1, TW_CP / 16, 4, P1>(pipe, smem, wave, lane, xin + (PITCH + 1) * XSTR, XSTR, acc, A);
             conv_epilogue<T, 4, false>(acc, smem, pout, h);
             lds_barrier();
         }
 
         // ---- 4c. policyconv2 (+bias): P -> logits L[board][pixel*73 + plane]    nn.cpp:75-79
         {
-            f32x16 acc[3];
-            acc_init<3>(acc, pbias2, h);
-            gemm_layer<T, 1, KH_POLICY_MID / 16, 3>(pipe, smem, wave, lane, pin, PSTR, acc);
+            f32x16 acc[4];                  // 73 planes padded to 128 rows: whole 2-k-step chunks
+            acc_init<4>(acc, pbias2, h);
+            gemm_layer<T, 1, KH_POLICY_MID / 16, 4, P1>(pipe, smem, wave, lane, pin, PSTR, acc, A);
+            if (P1) gemm_dummy<T, 1>(pipe, smem, wave, lane, A);      // stream parity back to 0 for the next group
             float* lrow = reinterpret_cast<float*>(smem + LDS_L + wb * LBOARD) + (py * 8 + px) * KH_POLICY_PLANES;
 #pragma unroll
-            for (int ms = 0; ms < 3; ++ms)
+            for (int ms = 0; ms < 3; ++ms)      // planes >= 96 are padding
 #pragma unroll
                 for (int g = 0; g < 4; ++g)
 #pragma unroll
