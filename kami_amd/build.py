@@ -22,6 +22,9 @@ OBJ = os.path.join(CSRC, "build")
 LIB = os.path.join(HERE, "libkamihip.so")
 ARCH = "gfx950"
 SOURCES = ["kh_api.hip", "encode.hip", "forward_simple.hip", "tower_mfma.hip"]
+# MFMA results in arch VGPRs: the epilogues read them with VALU ops and would otherwise pay a
+# v_accvgpr_read per value (the kernel runs one wave per SIMD, registers are not scarce).
+EXTRA_FLAGS = {"tower_mfma.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"]}
 HIPCC_FLAGS = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-Wall", "-Wno-unused-result",
                "-ffp-contract=fast"]
 
@@ -61,7 +64,7 @@ def build_all(force: bool = False, verbose: bool = False) -> str:
         o = os.path.join(OBJ, src.replace(".hip", ".o"))
         objs.append(o)
         if force or _stale(o, [s] + headers):
-            jobs.append([hipcc] + HIPCC_FLAGS + ["-c", s, "-o", o])
+            jobs.append([hipcc] + HIPCC_FLAGS + EXTRA_FLAGS.get(src, []) + ["-c", s, "-o", o])
 
     def run(cmd):
         if verbose:

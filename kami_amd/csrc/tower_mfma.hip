@@ -84,18 +84,37 @@ template <> struct Elem<_Float16> {
     static __device__ __forceinline__ f32x16 mfma(vec8 a, vec8 b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0); }
 };
 
-template <typename T> __device__ __forceinline__ unsigned pack2(float lo, float hi)
+// Two fp32 -> one dword of two T (round to nearest even), ONE instruction.  hipcc does not form the
+// packed convert from scalar casts + shifts here (it emits cvt, shift, or per pair), so it is asm.
+template <typename T> __device__ __forceinline__ unsigned pack2(float lo, float hi);
+template <> __device__ __forceinline__ unsigned pack2<__bf16>(float lo, float hi)
 {
-    T a = (T)lo, b = (T)hi;
-    return (unsigned)__builtin_bit_cast(unsigned short, a) | ((unsigned)__builtin_bit_cast(unsigned short, b) << 16);
+    unsigned r;
+    asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(lo), "v"(hi));
+    return r;
+}
+template <> __device__ __forceinline__ unsigned pack2<_Float16>(float lo, float hi)
+{
+    unsigned r;
+    asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(r) : "v"(lo), "v"(hi));
+    return r;
+}
+// ReLU on a packed pair of bf16 / f16: both formats keep the sign in bit 15, so a signed 16-bit
+// max with 0 clears negatives (and -0) and leaves everything else: one v_pk_max_i16 per 2 values.
+using short2_t = short __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ unsigned relu_pk(unsigned w)
+{
+    const short2_t z = { 0, 0 };
+    return __builtin_bit_cast(unsigned, __builtin_elementwise_max(__builtin_bit_cast(short2_t, w), z));
 }
 template <typename T> __device__ __forceinline__ float unpack_lo(unsigned u) { return (float)__builtin_bit_cast(T, (unsigned short)(u & 0xffffu)); }
 template <typename T> __device__ __forceinline__ float unpack_hi(unsigned u) { return (float)__builtin_bit_cast(T, (unsigned short)(u >> 16)); }
 
-// ReLU as one v_max_f32.  fmaxf drops a NaN operand (torch::relu keeps it), so the kernel guards
+// ReLU as one integer max.  It squashes negative-signed NaNs (torch::relu keeps NaN), so the kernel guards
 // the reference's NaN contract (nn.cpp:176-180) elsewhere: non-finite input planes are flagged
 // while they are converted, and the residual stream is checked for NaN/Inf after the tower.
-__device__ __forceinline__ float relu_nan(float v) { return fmaxf(v, 0.0f); }
+// (fp32: signed-integer max with 0 on the bits — one v_max_i32, no canonicalising pre-op.)
+__device__ __forceinline__ float relu_nan(float v) { const int i = __float_as_int(v); return __int_as_float(i > 0 ? i : 0); }
 
 // ---------------------------------------------------------------- weight stream (LDS-DMA ring)
 struct Pipe {
@@ -212,12 +231,17 @@ __device__ __forceinline__ void gemm_layer(Pipe& p, const char* smem, int wave, 
                 else acc[ms] = Elem<T>::mfma(A[cur][k * MS + ms], B[cur][k], acc[ms]);
             }
         // Pin the interleave: the next chunk's operand reads go out two per MFMA from the top of
-        // the step (hipcc would otherwise sink them to the end, exposing their latency at the
-        // next barrier); 2 ds_read_b128 per 32-cycle MFMA gap is within the LDS issue budget.
+        // the step.  Left alone hipcc sinks them to the end of the step and their latency lands on
+        // the next barrier; issued as one burst (DBG 512) they measured 8 % slower than paced.
+        if (DBG & 512) {
+            __builtin_amdgcn_sched_group_barrier(0x100, 8 + KPC, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);
+        } else {
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);   // DS read
-            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // MFMA
+            for (int i = 0; i < 8; ++i) {
+                __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);   // DS read
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // MFMA
+            }
         }
     }
 }
@@ -255,16 +279,18 @@ __device__ __forceinline__ void conv_epilogue(const f32x16 (&acc)[MS], char* sme
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
             const unsigned addr = out_pix + (ms * 32 + 8 * g + 4 * h) * 2;
-            float v0 = relu_nan(acc[ms][4 * g + 0]), v1 = relu_nan(acc[ms][4 * g + 1]);
-            float v2 = relu_nan(acc[ms][4 * g + 2]), v3 = relu_nan(acc[ms][4 * g + 3]);
+            u32x2 o;
             if (SKIP) {
                 const u32x2 old = *reinterpret_cast<const u32x2*>(smem + addr);
-                v0 += unpack_lo<T>(old.x); v1 += unpack_hi<T>(old.x);
-                v2 += unpack_lo<T>(old.y); v3 += unpack_hi<T>(old.y);
+                o.x = pack2<T>(relu_nan(acc[ms][4 * g + 0]) + unpack_lo<T>(old.x), relu_nan(acc[ms][4 * g + 1]) + unpack_hi<T>(old.x));
+                o.y = pack2<T>(relu_nan(acc[ms][4 * g + 2]) + unpack_lo<T>(old.y), relu_nan(acc[ms][4 * g + 3]) + unpack_hi<T>(old.y));
+            } else {
+                // relu_nan first: it is compiler-visible, so hipcc pads the MFMA-result -> VALU-read
+                // hazard for it; the asm convert then only ever reads VALU results (hipcc cannot
+                // see into an asm statement and would not pad an MFMA -> asm dependency)
+                o.x = pack2<T>(relu_nan(acc[ms][4 * g + 0]), relu_nan(acc[ms][4 * g + 1]));
+                o.y = pack2<T>(relu_nan(acc[ms][4 * g + 2]), relu_nan(acc[ms][4 * g + 3]));
             }
-            u32x2 o;
-            o.x = pack2<T>(v0, v1);
-            o.y = pack2<T>(v2, v3);
             *reinterpret_cast<u32x2*>(smem + addr) = o;
         }
 }
@@ -617,6 +643,7 @@ hipError_t launch_tower(int dtype, int FP, const TowerArgs& a, int num_cus, hipS
         case 128: return launch<__bf16, 8, 128>(a, grid, s);
         case 256: return launch<__bf16, 8, 256>(a, grid, s);
         case 448: return launch<__bf16, 8, 448>(a, grid, s);
+        case 512: return launch<__bf16, 8, 512>(a, grid, s);
         default: break;
         }
     }
