@@ -123,6 +123,8 @@ struct Pipe {
     int next;               // chunk index to issue next
     int islot, cslot;       // ring slots: next to fill / next to consume
     unsigned ring;          // LDS byte offset of the ring
+    unsigned long long* stamps;   // DBG 1024 only: s_memtime before / after every step barrier
+    int nstep;
 };
 
 __device__ __forceinline__ void glds16(const char* gsrc, unsigned lds_dst)
@@ -157,8 +159,19 @@ __device__ __forceinline__ void pipe_issue(Pipe& p, int wave, int lane)
 template <int DBG = 0>
 __device__ __forceinline__ unsigned pipe_step(Pipe& p, int wave, int lane)
 {
+    unsigned long long t0 = 0, t1 = 0;
+    if (DBG & 1024) t0 = __builtin_amdgcn_s_memtime();
     if (!(DBG & 4)) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * (RING_D - 3)) : "memory");
+    if (DBG & 1024) t1 = __builtin_amdgcn_s_memtime();
     if (!(DBG & 1)) asm volatile("s_barrier" ::: "memory");
+    if (DBG & 1024) {
+        const unsigned long long t2 = __builtin_amdgcn_s_memtime();
+        if (p.stamps && lane == 0 && p.nstep < 256) {
+            unsigned long long* d = p.stamps + ((size_t)wave * 256 + p.nstep) * 3;
+            d[0] = t0; d[1] = t1; d[2] = t2;
+        }
+        ++p.nstep;
+    }
     // Nothing moves across the step boundary: hipcc otherwise hoists the next step's MFMAs up to
     // their operand loads and the register double-buffering collapses into load->wait->MFMA.
     __builtin_amdgcn_sched_barrier(0);
@@ -353,6 +366,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     Pipe pipe;
     pipe.stream = a.wstream; pipe.nch = a.nchunks; pipe.next = 0; pipe.islot = 0; pipe.cslot = 0;
     pipe.ring = LDS_RING;
+    pipe.stamps = ((DBG & 1024) && blockIdx.x == 0) ? reinterpret_cast<unsigned long long*>(a.logits) : nullptr;
+    pipe.nstep = 0;
 #pragma unroll
     for (int i = 0; i < RING_D - 1; ++i) pipe_issue(pipe, wave, lane);
 
@@ -442,7 +457,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         {
             f32x16 acc[2];
             acc_init<2>(acc, shift3, h);
-            gemm_layer<T, 9, KS_STEM, 2, 0>(pipe, smem, wave, lane, sin, SSTR, acc, A);
+            gemm_layer<T, 9, KS_STEM, 2, 0, DBG & 1024>(pipe, smem, wave, lane, sin, SSTR, acc, A);
             conv_epilogue<T, 2, false>(acc, smem, xout, h);
             lds_barrier();
             // T shares LDS with S: clear T's halo before the tower reads through it
@@ -494,7 +509,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         {
             f32x16 acc[4];
             acc_init<4>(acc, pshift1, h);
-            gemm_layer<T, 1, TW_CP / 16, 4, P1>(pipe, smem, wave, lane, xin + (PITCH + 1) * XSTR, XSTR, acc, A);
+            gemm_layer<T, 1, TW_CP / 16, 4, P1, DBG & 1024>(pipe, smem, wave, lane, xin + (PITCH + 1) * XSTR, XSTR, acc, A);
             conv_epilogue<T, 4, false>(acc, smem, pout, h);
             lds_barrier();
         }
@@ -503,7 +518,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         {
             f32x16 acc[4];                  // 73 planes padded to 128 rows: whole 2-k-step chunks
             acc_init<4>(acc, pbias2, h);
-            gemm_layer<T, 1, KH_POLICY_MID / 16, 4, P1>(pipe, smem, wave, lane, pin, PSTR, acc, A);
+            gemm_layer<T, 1, KH_POLICY_MID / 16, 4, P1, DBG & 1024>(pipe, smem, wave, lane, pin, PSTR, acc, A);
             if (P1) gemm_dummy<T, 1>(pipe, smem, wave, lane, A);      // stream parity back to 0 for the next group
             float* lrow = reinterpret_cast<float*>(smem + LDS_L + wb * LBOARD) + (py * 8 + px) * KH_POLICY_PLANES;
 #pragma unroll
@@ -531,7 +546,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                 const int q = tt + 128 * k;
                 v[k] = (q < NQ) ? L4[q] : make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
             }
-            if (a.logits && live) {
+            if (a.logits && live && !(DBG & 1024)) {
                 float4* lo = reinterpret_cast<float4*>(a.logits + (size_t)(b0 + bb) * KH_PSIZE);
 #pragma unroll
                 for (int k = 0; k < 10; ++k)
@@ -644,6 +659,11 @@ hipError_t launch_tower(int dtype, int FP, const TowerArgs& a, int num_cus, hipS
         case 256: return launch<__bf16, 8, 256>(a, grid, s);
         case 448: return launch<__bf16, 8, 448>(a, grid, s);
         case 512: return launch<__bf16, 8, 512>(a, grid, s);
+        case 1024: return launch<__bf16, 8, 1024>(a, grid, s);
+        case 26: return launch<__bf16, 8, 26>(a, grid, s);
+        case 34: return launch<__bf16, 8, 34>(a, grid, s);
+        case 56: return launch<__bf16, 8, 56>(a, grid, s);
+        case 27: return launch<__bf16, 8, 27>(a, grid, s);
         default: break;
         }
     }
