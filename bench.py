@@ -72,20 +72,14 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     a = ap.parse_args()
 
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-
     import torch
-    from kami_amd import NN, weights as W, _lib as L
+    from kami_amd import NN, weights as W, _lib as L, dist as kd
 
+    rank, local_rank, world = kd.env_rank()
     if not torch.cuda.is_available():
         sys.exit("bench.py needs a GPU (the engine has no CPU path)")
     torch.cuda.set_device(local_rank)
-    dist = None
-    if world > 1:
-        import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    dist = kd.init("nccl")          # RCCL; only the barrier and the max-over-ranks use it
 
     F, Cc, R, B = a.features, a.filters, a.residuals, a.batch
     nn = NN(8, 8, F, 4672, filters=Cc, residuals=R, dtype=a.dtype, device=local_rank)
@@ -107,8 +101,7 @@ def main():
             raise RuntimeError(L.last_error())
 
     def barrier():
-        if dist is not None:
-            dist.barrier()
+        kd.barrier(dist)
         torch.cuda.synchronize()
 
     for _ in range(a.warmup):
@@ -118,14 +111,9 @@ def main():
     for _ in range(a.steps):
         step()
     torch.cuda.synchronize()
-    if dist is not None:
-        dist.barrier()
-    torch.cuda.synchronize()
+    barrier()
     dt = time.perf_counter() - t0
-    if dist is not None:
-        t = torch.tensor([dt], device="cuda", dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+    dt = kd.max_over_ranks(dist, dt, device="cuda")
     assert bool(torch.isfinite(policy).all()) and abs(float(policy[0].sum()) - 1.0) < 1e-2
 
     # roofline of the dominant kernel (the forward pass), HIP events on the engine's own stream

@@ -1,0 +1,59 @@
+"""One process per GPU: the little that the leaf-evaluation path needs from torch.distributed.
+
+Leaf evaluations are independent, so ranks shard units (boards / games) and never
+exchange data on the evaluation path; the only collectives are the barrier and the
+max-over-ranks of the elapsed time that the benchmark contract asks for, and — outside the timed
+path — the replay-record gather (replay.py).  Backend "nccl" is RCCL on ROCm; "gloo" is used by
+the CPU tests.
+"""
+from __future__ import annotations
+
+import os
+from typing import Tuple
+
+
+def env_rank() -> Tuple[int, int, int]:
+    """(rank, local_rank, world_size) from the torchrun environment (defaults: single process)."""
+    return (int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", "0")),
+            int(os.environ.get("WORLD_SIZE", "1")))
+
+
+def init(backend: str | None = None):
+    """Initialise the default process group when WORLD_SIZE > 1; returns torch.distributed or None."""
+    rank, local_rank, world = env_rank()
+    if world <= 1:
+        return None
+    import torch
+    import torch.distributed as dist
+    if dist.is_initialized():
+        return dist
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29500")
+    if backend is None:
+        backend = "nccl" if torch.cuda.is_available() else "gloo"
+    if backend == "nccl":
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    else:
+        dist.init_process_group(backend)
+    return dist
+
+
+def shard(n_units: int, rank: int, world: int) -> Tuple[int, int]:
+    """Contiguous, balanced split of n_units over world ranks -> (start, count) of this rank."""
+    base, extra = divmod(n_units, world)
+    start = rank * base + min(rank, extra)
+    return start, base + (1 if rank < extra else 0)
+
+
+def barrier(dist) -> None:
+    if dist is not None:
+        dist.barrier()
+
+
+def max_over_ranks(dist, value: float, device: str = "cpu") -> float:
+    if dist is None:
+        return value
+    import torch
+    t = torch.tensor([value], dtype=torch.float64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())
