@@ -59,6 +59,24 @@ def cpu_baseline(F, Cc, R, batch):
             "kind": "port", "sample": f"one oracle forward over {n} boards of 8x8x{F}, {R}x{Cc} net (OpenMP)"}
 
 
+def measured_traffic(F, Cc, R, B, dtype):
+    """HBM bytes per launch of the forward kernel from the PMC passes kept under profiles/
+    (FETCH_SIZE / WRITE_SIZE, separate rocprofv3 --pmc runs, gfx950 corrections applied as
+    MI355X_MICROARCH.md prescribes).  Counters cannot be read from inside this process, so this
+    is the committed measurement of the SAME command; None when the workload differs."""
+    import glob
+    best = None
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_summary.json"))):
+        try:
+            d = json.load(open(path))
+        except Exception:
+            continue
+        w = d.get("workload_key", {})
+        if w == {"features": F, "filters": Cc, "residuals": R, "batch": B, "dtype": dtype}:
+            best = d["hbm_traffic"]["total_bytes_per_launch"]
+    return best
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -140,7 +158,8 @@ def main():
                        "batch_per_gpu": B, "features": F, "filters": Cc, "residuals": R,
                        "parallelism": f"replicas x{world}, no data-path collective"},
             "roofline": {"bound": "mfma", "achieved": round(achieved, 3), "peak": peak, "unit": "TFLOP/s",
-                         "frac": round(achieved / peak, 5), "traffic": None,
+                         "frac": round(achieved / peak, 5),
+                         "traffic": measured_traffic(F, Cc, R, B, a.dtype),
                          "kernel_ms": round(ms.value, 5),
                          "flops_per_launch": flops},
         }
