@@ -127,21 +127,21 @@ struct Pipe {
     int nstep;
 };
 
-__device__ __forceinline__ void glds16(const char* gsrc, unsigned lds_dst)
-{
-    // LDS-DMA: 64 lanes x 16 B -> LDS[M0 + lane*16].  M0 is written in the same statement that
-    // reads it and restored (cdna_hip_programming.md §5.7).
-    unsigned keep;
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
-                 : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
-}
-
+// One wave's quarter of a chunk: two 1 KB LDS-DMA pieces (64 lanes x 16 B each -> LDS[M0 + inst
+// offset + lane*16]).  Scalar base + one constant per-lane offset: no address VALU work per step;
+// the instruction offset moves the global AND the LDS address (verified on gfx950,
+// tools/glds_test.hip).  M0 is written in the same statement that reads it and restored
+// (cdna_hip_programming.md §5.7).
 __device__ __forceinline__ void pipe_issue(Pipe& p, int wave, int lane)
 {
-    const char* src = p.stream + (size_t)p.next * CHUNK + wave * 2048 + lane * 16;
+    const char* sbase = p.stream + (size_t)p.next * CHUNK + wave * 2048;      // wave-uniform -> SGPR pair
     const unsigned dst = p.ring + p.islot * CHUNK + wave * 2048;
-    glds16(src, dst);
-    glds16(src + 1024, dst + 1024);
+    const unsigned voff = lane * 16;
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\t"
+                 "global_load_lds_dwordx4 %1, %2\n\tglobal_load_lds_dwordx4 %1, %2 offset:1024\n\t"
+                 "s_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(voff), "s"(sbase), "s"(dst) : "memory");
     p.next = (p.next + 1 == p.nch) ? 0 : p.next + 1;
     p.islot = (p.islot + 1 == RING_D) ? 0 : p.islot + 1;
 }

@@ -8,9 +8,10 @@ nn = NN(8, 8, F, 4672, filters=Cc, residuals=R, dtype="bf16")
 nn.load_weights(W.random_weights(F, Cc, R, seed=1), 1)
 lib = L.load()
 x = torch.rand((B, 8, 8, F), device="cuda"); pol = torch.empty((B, 4672), device="cuda"); vf = torch.empty((B, 256), device="cuda")
-for S in (1, 2, 4):
+for S in (1, 2, 4, 8, 16, 1, 4, 8):
     streams = [torch.cuda.Stream() for _ in range(S)]
     sub = B // S
+    assert sub * S == B
     def step():
         for i, st in enumerate(streams):
             rc = lib.kh_infer_device(nn.handle, C.c_void_p(x[i*sub:].data_ptr()), sub, C.c_void_p(pol[i*sub:].data_ptr()),
