@@ -132,6 +132,20 @@ int  kh_encode(kh_engine* e, const kh_board* boards, int batch, float* planes);
 int  kh_encode_infer(kh_engine* e, const kh_board* boards, int batch,
                      float* policy, float* value);
 
+/* Legal-move policy gather: what MCTS::expand does with the network output (mcts.h:273-276,296)
+ * moved to the device, so that only the priors of each position's legal actions cross PCIe
+ * instead of 4672 floats.  Position i owns actions[action_offsets[i] .. action_offsets[i+1]) (action
+ * codes as produced by Env::actions, env.h:398-423);
+ *   priors[k] = policy_i[actions[k]] / sum_j policy_i[actions[j]]      (all zeros if the sum is 0)
+ * `value` as in kh_infer.  The noise mixing of mcts.h:279-296 stays with the caller.
+ * kh_infer_legal takes fp32 planes, kh_encode_infer_legal takes compact board records. */
+int  kh_infer_legal(kh_engine* e, const float* input, int batch,
+                    const int32_t* action_offsets, const int32_t* actions,
+                    float* priors, float* value);
+int  kh_encode_infer_legal(kh_engine* e, const kh_board* boards, int batch,
+                           const int32_t* action_offsets, const int32_t* actions,
+                           float* priors, float* value);
+
 /* Device-resident variants (pointers are HIP device pointers, `stream` is a
  * hipStream_t or NULL for the engine's own stream).  Asynchronous: no host sync,
  * no NaN check.  d_value_full is [batch][256]. */

@@ -42,6 +42,8 @@ SYMBOLS = {
     "kh_infer_full": (C.c_int, [_P, _P, C.c_int, _P, _P, _P]),
     "kh_encode": (C.c_int, [_P, _P, C.c_int, _P]),
     "kh_encode_infer": (C.c_int, [_P, _P, C.c_int, _P, _P]),
+    "kh_infer_legal": (C.c_int, [_P, _P, C.c_int, _P, _P, _P, _P]),
+    "kh_encode_infer_legal": (C.c_int, [_P, _P, C.c_int, _P, _P, _P, _P]),
     "kh_infer_device": (C.c_int, [_P, _P, C.c_int, _P, _P, _P]),
     "kh_encode_device": (C.c_int, [_P, _P, C.c_int, _P, _P]),
     "kh_time_infer_device": (C.c_int, [_P, _P, C.c_int, _P, _P, C.c_int, C.POINTER(C.c_float)]),

@@ -81,4 +81,41 @@ void launch_encode_f32(const kh_board* d_boards, int n, float* d_planes, hipStre
                        ENC_WAVES * ENC_TILE * sizeof(float), s, d_boards, n, d_planes);
 }
 
+// ---------------------------------------------------------------------------------------------
+// Legal-move policy gather (MCTS::expand, kami/mcts.h:273-276,296): one wavefront per position,
+// lanes stride over the position's legal actions (<= 128 in the reference, any count here).
+__global__ __launch_bounds__(256) void gather_legal_kernel(const float* __restrict__ policy,
+                                                           const int32_t* __restrict__ offsets,
+                                                           const int32_t* __restrict__ actions,
+                                                           float* __restrict__ priors, int B)
+{
+    const int lane = threadIdx.x & 63;
+    const int wpb = blockDim.x >> 6;
+    for (int b = blockIdx.x * wpb + (threadIdx.x >> 6); b < B; b += gridDim.x * wpb) {
+        const int lo = offsets[b], hi = offsets[b + 1];
+        const float* p = policy + (size_t)b * KH_PSIZE;
+        float sum = 0.0f;
+        for (int k = lo + lane; k < hi; k += 64) {
+            const int a = actions[k];
+            sum += (a >= 0 && a < KH_PSIZE) ? p[a] : 0.0f;
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o, 64);
+        const float inv = sum > 0.0f ? 1.0f / sum : 0.0f;
+        for (int k = lo + lane; k < hi; k += 64) {
+            const int a = actions[k];
+            priors[k] = (a >= 0 && a < KH_PSIZE) ? p[a] * inv : 0.0f;
+        }
+    }
+}
+
+void launch_gather_legal(const float* policy, const int32_t* offsets, const int32_t* actions,
+                         float* priors, int B, hipStream_t s)
+{
+    if (B <= 0) return;
+    int blocks = (B + 3) / 4;
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(gather_legal_kernel, dim3(blocks), dim3(256), 0, s, policy, offsets, actions, priors, B);
+}
+
 }  // namespace kh

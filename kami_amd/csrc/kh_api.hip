@@ -255,7 +255,7 @@ int build_simple(Weights& W, const HostNet& n, int F, int C, int R)
 struct Slot {
     hipStream_t stream = nullptr;
     int cap = 0;                 // boards the scratch is sized for
-    DevMem in, x, t, u, ph, logits, policy, v64, vfull, flags, boards, planes;
+    DevMem in, x, t, u, ph, logits, policy, v64, vfull, flags, boards, planes, offs, acts, priors;
     bool busy = false;
     bool flags_clean = false;    // device NaN flags known to be zero
 };
@@ -410,12 +410,22 @@ int check_cfg(const kh_config* c)
     return KH_OK;
 }
 
+struct LegalIO { const int32_t* offsets; const int32_t* actions; float* priors; };
+
 int infer_host(kh_engine* e, const float* input, const kh_board* boards, int batch,
-               float* policy, float* value, float* value_full, float* logits)
+               float* policy, float* value, float* value_full, float* logits, const LegalIO* legal = nullptr)
 {
     if (!e) return fail(KH_ERR_INVALID, "null engine");
     if (batch < 1) return fail(KH_ERR_INVALID, "batch must be >= 1 (got %d)", batch);
-    if ((!input && !boards) || !policy) return fail(KH_ERR_INVALID, "null buffer");
+    if ((!input && !boards) || (!policy && !legal)) return fail(KH_ERR_INVALID, "null buffer");
+    int nact = 0;
+    if (legal) {
+        if (!legal->offsets || !legal->actions || !legal->priors) return fail(KH_ERR_INVALID, "null legal-move buffer");
+        if (legal->offsets[0] != 0) return fail(KH_ERR_INVALID, "action_offsets[0] must be 0");
+        for (int i = 0; i < batch; ++i)
+            if (legal->offsets[i + 1] < legal->offsets[i]) return fail(KH_ERR_INVALID, "action_offsets must be non-decreasing");
+        nact = legal->offsets[batch];
+    }
     std::shared_ptr<Weights> W = current_weights(e);
     if (!W) return fail(KH_ERR_NO_WEIGHTS, "kh_infer before kh_load_weights");
     int rc = set_device(e);
@@ -438,7 +448,15 @@ int infer_host(kh_engine* e, const float* input, const kh_board* boards, int bat
     if ((rc = forward_dispatch(e, *W, s, d_in, batch, s.policy.as<float>(), s.vfull.as<float>(), d_logits)))
         return rc;
     int flags[4] = { 0, 0, 0, 0 };
-    HIPCHK(hipMemcpyAsync(policy, s.policy.p, B * KH_PSIZE * 4, hipMemcpyDeviceToHost, st));  // nn.cpp:173,185
+    if (legal && nact > 0) {
+        if (s.offs.ensure((B + 1) * 4) || s.acts.ensure((size_t)nact * 4) || s.priors.ensure((size_t)nact * 4)) return KH_ERR_HIP;
+        HIPCHK(hipMemcpyAsync(s.offs.p, legal->offsets, (B + 1) * 4, hipMemcpyHostToDevice, st));
+        HIPCHK(hipMemcpyAsync(s.acts.p, legal->actions, (size_t)nact * 4, hipMemcpyHostToDevice, st));
+        kh::launch_gather_legal(s.policy.as<float>(), s.offs.as<int32_t>(), s.acts.as<int32_t>(), s.priors.as<float>(), batch, st);
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipMemcpyAsync(legal->priors, s.priors.p, (size_t)nact * 4, hipMemcpyDeviceToHost, st));
+    }
+    if (policy) HIPCHK(hipMemcpyAsync(policy, s.policy.p, B * KH_PSIZE * 4, hipMemcpyDeviceToHost, st));  // nn.cpp:173,185
     if (logits) HIPCHK(hipMemcpyAsync(logits, s.logits.p, B * KH_PSIZE * 4, hipMemcpyDeviceToHost, st));
     if (value_full)
         HIPCHK(hipMemcpyAsync(value_full, s.vfull.p, B * KH_VALUE_WIDTH * 4, hipMemcpyDeviceToHost, st));
@@ -580,6 +598,25 @@ int kh_encode_infer(kh_engine* e, const kh_board* boards, int batch, float* poli
         return fail(KH_ERR_INVALID, "kh_encode_infer needs features == %d (Env::observe planes)", KH_NFEATURES);
     if (!value || !boards) return fail(KH_ERR_INVALID, "null buffer");
     return infer_host(e, nullptr, boards, batch, policy, value, nullptr, nullptr);
+}
+
+int kh_infer_legal(kh_engine* e, const float* input, int batch, const int32_t* action_offsets,
+                   const int32_t* actions, float* priors, float* value)
+{
+    if (!value || !input) return fail(KH_ERR_INVALID, "null buffer");
+    LegalIO l{ action_offsets, actions, priors };
+    return infer_host(e, input, nullptr, batch, nullptr, value, nullptr, nullptr, &l);
+}
+
+int kh_encode_infer_legal(kh_engine* e, const kh_board* boards, int batch, const int32_t* action_offsets,
+                          const int32_t* actions, float* priors, float* value)
+{
+    if (!e) return fail(KH_ERR_INVALID, "null engine");
+    if (e->cfg.features != KH_NFEATURES)
+        return fail(KH_ERR_INVALID, "kh_encode_infer_legal needs features == %d (Env::observe planes)", KH_NFEATURES);
+    if (!value || !boards) return fail(KH_ERR_INVALID, "null buffer");
+    LegalIO l{ action_offsets, actions, priors };
+    return infer_host(e, nullptr, boards, batch, nullptr, value, nullptr, nullptr, &l);
 }
 
 int kh_encode(kh_engine* e, const kh_board* boards, int batch, float* planes)

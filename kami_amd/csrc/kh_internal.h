@@ -13,6 +13,10 @@ namespace kh {
 // Env::observe (kami/env.h:202-262) for n records -> fp32 planes [n][8][8][30].
 void launch_encode_f32(const kh_board* d_boards, int n, float* d_planes, hipStream_t s);
 
+// priors[k] = policy[i][actions[k]] / sum over position i's actions (mcts.h:273-276); one wave per position
+void launch_gather_legal(const float* policy, const int32_t* offsets, const int32_t* actions,
+                         float* priors, int B, hipStream_t s);
+
 // ---- forward_simple.hip -----------------------------------------------------------------
 // Plain fp32 VALU kernels, one launch per layer.  Exact-order fp32 (same tap-major,
 // channel-inner accumulation order as the CPU oracle); the correctness anchor on device.

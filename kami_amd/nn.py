@@ -133,6 +133,22 @@ class NN:
         _chk(self._lib.kh_encode_infer(self._h, _ptr(b), n, _ptr(policy), _ptr(value)))
         return policy, value
 
+    def infer_legal(self, input_or_boards: np.ndarray, action_offsets: np.ndarray, actions: np.ndarray):
+        """Legal-move policy gather (MCTS::expand, mcts.h:273-276): -> (priors [sum of counts], value [B]).
+        `input_or_boards` is either fp32 planes [B,8,8,F] or kh_board records."""
+        offs = np.ascontiguousarray(action_offsets, dtype=np.int32)
+        acts = np.ascontiguousarray(actions, dtype=np.int32)
+        n = offs.size - 1
+        priors = np.empty((int(offs[-1]),), np.float32)
+        value = np.empty((n,), np.float32)
+        if input_or_boards.dtype == L.BOARD_DTYPE:
+            b = np.ascontiguousarray(input_or_boards)
+            _chk(self._lib.kh_encode_infer_legal(self._h, _ptr(b), n, _ptr(offs), _ptr(acts), _ptr(priors), _ptr(value)))
+        else:
+            x = np.ascontiguousarray(input_or_boards, dtype=np.float32)
+            _chk(self._lib.kh_infer_legal(self._h, _ptr(x), n, _ptr(offs), _ptr(acts), _ptr(priors), _ptr(value)))
+        return priors, value
+
     @property
     def handle(self):
         return self._h

@@ -197,6 +197,43 @@ def test_encode_infer_equals_encode_then_infer(observe_fixture):
     assert np.array_equal(p1, p2) and np.array_equal(v1, v2)
 
 
+def test_legal_move_gather_matches_expand_renormalisation(observe_fixture):
+    """priors = policy[legal] / sum(policy[legal]) (MCTS::expand, mcts.h:273-276,296) with the
+    reference's own legal-action lists (Env::actions) from the fixture."""
+    f = observe_fixture
+    sel = np.arange(0, len(f["fen"]), 9)[:100]
+    boards = ko.boards_from_fens([f["fen"][i].decode() for i in sel], f["ply"][sel])
+    nact = f["nact"][sel].astype(np.int64)
+    offs = np.concatenate([[0], np.cumsum(nact)]).astype(np.int32)
+    acts = np.concatenate([f["actions"][i, :f["nact"][i]] for i in sel]).astype(np.int32)
+    F, C, R = 30, 32, 1
+    blob = W.random_weights(F, C, R, seed=21, peaky=20.0)
+    for dtype in ("f32", "bf16"):
+        nn = NN(8, 8, F, 4672, filters=C, residuals=R, dtype=dtype)
+        nn.load_weights(blob, 1)
+        priors, value = nn.infer_legal(boards, offs, acts)
+        policy, value2 = nn.encode_infer(boards)
+        assert np.array_equal(value, value2)
+        for i in range(len(sel)):
+            a = acts[offs[i]:offs[i + 1]]
+            if len(a) == 0:
+                continue
+            want = policy[i, a] / policy[i, a].sum(dtype=np.float32)
+            np.testing.assert_allclose(priors[offs[i]:offs[i + 1]], want, rtol=2e-6, atol=1e-9)
+            assert abs(priors[offs[i]:offs[i + 1]].sum() - 1.0) < 1e-5
+        # planes entry point agrees with the compact one
+        pr2, _ = nn.infer_legal(nn.encode(boards), offs, acts)
+        assert np.array_equal(pr2, priors)
+    # against the oracle end to end (f32)
+    nn = NN(8, 8, F, 4672, filters=C, residuals=R, dtype="f32")
+    nn.load_weights(blob, 1)
+    priors, _ = nn.infer_legal(boards, offs, acts)
+    op, _, _ = ko.forward(blob, F, C, R, ko.observe(boards))
+    i = int(np.argmax(nact))
+    a = acts[offs[i]:offs[i + 1]]
+    np.testing.assert_allclose(priors[offs[i]:offs[i + 1]], op[i, a] / op[i, a].sum(), rtol=1e-3)
+
+
 # ------------------------------------------------------------------------------ boundary behaviour
 def test_nan_guard_and_errors():
     F, C, R = 30, 8, 0
