@@ -103,6 +103,12 @@ struct Weights {
     int tw_nchunks = 0, tw_npar = 0, tw_FP = 0;
     bool tw_ok = false;
     std::string tw_why;
+    // per-layer MFMA path for wide nets (layers_mfma.hip)
+    DevMem ly_w, ly_shift, ly_misc;      // ly_misc: vw[CP], fcw[256*64], fcb[256]
+    std::vector<size_t> ly_w_off, ly_shift_off;
+    int ly_FP = 0, ly_CP = 0;
+    float ly_vshift = 0.0f;
+    bool ly_ok = false;
 };
 
 // Eval-mode BatchNorm folded to an epilogue (scale, shift):
@@ -151,6 +157,59 @@ void pack_layer(std::vector<uint16_t>& out, int dtype, const float* w, const flo
                     }
                 }
     while (out.size() % 4096) out.push_back(0);
+}
+
+// Fragments of one layer for layers_mfma.hip: [Co/64][tap][Ci/16][2][lane][8], BN scale folded in.
+void pack_layer_generic(std::vector<uint16_t>& out, int dtype, const float* w, const float* scale,
+                        int Co, int Ci, int taps, int CoP, int CiP)
+{
+    for (int cb = 0; cb < CoP / 64; ++cb)
+        for (int tap = 0; tap < taps; ++tap)
+            for (int ks = 0; ks < CiP / 16; ++ks)
+                for (int ms = 0; ms < 2; ++ms)
+                    for (int l = 0; l < 64; ++l) {
+                        const int r = l & 31, h = l >> 5;
+                        for (int j = 0; j < 8; ++j) {
+                            const int co = cb * 64 + ms * 32 + r, ci = ks * 16 + 8 * h + j;
+                            float v = 0.0f;
+                            if (co < Co && ci < Ci) v = w[((size_t)co * Ci + ci) * taps + tap] * (scale ? scale[co] : 1.0f);
+                            out.push_back(dtype == KH_BF16 ? f2bf16(v) : f2f16(v));
+                        }
+                    }
+}
+
+int build_layers(Weights& W, const HostNet& n, int dtype, int F, int C, int R)
+{
+    const int FP = (F + 15) / 16 * 16, CP = (C + 63) / 64 * 64;
+    if (CP > 256 || FP > 256) return KH_OK;              // not covered: ly_ok stays false
+    std::vector<uint16_t> w;
+    std::vector<float> shift;
+    std::vector<float> sc(256), sh(256);
+    auto add = [&](const float* wt, const ConvBN* bn, const float* bias, int Co, int Ci, int taps, int CoP, int CiP) {
+        W.ly_w_off.push_back(w.size());
+        W.ly_shift_off.push_back(shift.size());
+        if (bn) fold_bn(*bn, Co, sc.data(), sh.data());
+        else for (int i = 0; i < Co; ++i) { sc[i] = 1.0f; sh[i] = bias[i]; }
+        pack_layer_generic(w, dtype, wt, sc.data(), Co, Ci, taps, CoP, CiP);
+        for (int i = 0; i < CoP; ++i) shift.push_back(i < Co ? sh[i] : 0.0f);
+    };
+    add(n.stem.w, &n.stem, nullptr, C, F, 9, CP, FP);
+    for (int i = 0; i < 2 * R; ++i) add(n.res[i].w, &n.res[i], nullptr, C, C, 9, CP, CP);
+    add(n.pconv.w, &n.pconv, nullptr, KH_POLICY_MID, C, 1, KH_POLICY_MID, CP);
+    add(n.p2w, nullptr, n.p2b, KH_POLICY_PLANES, KH_POLICY_MID, 1, 128, KH_POLICY_MID);
+    std::vector<float> misc((size_t)CP + KH_VALUE_WIDTH * 64 + KH_VALUE_WIDTH, 0.0f);
+    float vs, vsh;
+    fold_bn(n.vconv, 1, &vs, &vsh);
+    for (int i = 0; i < C; ++i) misc[i] = n.vconv.w[i] * vs;
+    memcpy(misc.data() + CP, n.fcw, sizeof(float) * KH_VALUE_WIDTH * 64);
+    memcpy(misc.data() + CP + (size_t)KH_VALUE_WIDTH * 64, n.fcb, sizeof(float) * KH_VALUE_WIDTH);
+    W.ly_vshift = vsh; W.ly_FP = FP; W.ly_CP = CP;
+    if (W.ly_w.ensure(w.size() * 2) || W.ly_shift.ensure(shift.size() * 4) || W.ly_misc.ensure(misc.size() * 4)) return KH_ERR_HIP;
+    HIPCHK(hipMemcpy(W.ly_w.p, w.data(), w.size() * 2, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(W.ly_shift.p, shift.data(), shift.size() * 4, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(W.ly_misc.p, misc.data(), misc.size() * 4, hipMemcpyHostToDevice));
+    W.ly_ok = true;
+    return KH_OK;
 }
 
 int build_tower(Weights& W, const HostNet& n, int dtype, int F, int C, int R)
@@ -255,7 +314,7 @@ int build_simple(Weights& W, const HostNet& n, int F, int C, int R)
 struct Slot {
     hipStream_t stream = nullptr;
     int cap = 0;                 // boards the scratch is sized for
-    DevMem in, x, t, u, ph, logits, policy, v64, vfull, flags, boards, planes, offs, acts, priors;
+    DevMem in, x, t, u, ph, logits, policy, v64, vfull, flags, boards, planes, offs, acts, priors, actin;
     bool busy = false;
     bool flags_clean = false;    // device NaN flags known to be zero
 };
@@ -383,13 +442,52 @@ int forward_tower(kh_engine* e, const Weights& W, Slot& s, const float* d_in, in
     return KH_OK;
 }
 
+// Wide nets in bf16 / f16: one MFMA launch per layer (layers_mfma.hip), then the shared softmax / FC kernels.
+int forward_layers(kh_engine* e, const Weights& W, Slot& s, const float* d_in, int B,
+                   float* d_policy, float* d_vfull, float* d_logits_out)
+{
+    const size_t nb = B;
+    int rc = 0;
+    rc |= s.actin.ensure(nb * 64 * W.ly_FP * 2);
+    rc |= s.x.ensure(nb * 64 * W.ly_CP * 2);
+    rc |= s.t.ensure(nb * 64 * W.ly_CP * 2);
+    rc |= s.u.ensure(nb * 64 * W.ly_CP * 2);
+    rc |= s.ph.ensure(nb * 64 * KH_POLICY_MID * 2);
+    rc |= s.logits.ensure(nb * KH_PSIZE * 4);
+    rc |= s.v64.ensure(nb * 64 * 4);
+    rc |= s.flags.ensure(16);
+    if (rc) return KH_ERR_HIP;
+    hipStream_t st = s.stream;
+    int* flags = s.flags.as<int>();
+    HIPCHK(hipMemsetAsync(flags, 0, 16, st));
+    s.flags_clean = false;
+    kh::LayersArgs L;
+    L.in = d_in; L.B = B; L.F = e->cfg.features; L.FP = W.ly_FP; L.CP = W.ly_CP; L.R = e->cfg.residuals;
+    L.act_in = s.actin.as<unsigned short>();
+    L.act[0] = s.x.as<unsigned short>(); L.act[1] = s.t.as<unsigned short>(); L.act[2] = s.u.as<unsigned short>();
+    L.pmid = s.ph.as<unsigned short>();
+    L.logits = d_logits_out ? d_logits_out : s.logits.as<float>();
+    L.v64 = s.v64.as<float>();
+    L.w = W.ly_w.as<unsigned short>(); L.w_off = W.ly_w_off.data();
+    L.shift = W.ly_shift.as<float>(); L.shift_off = W.ly_shift_off.data();
+    L.vw = W.ly_misc.as<float>(); L.vshift = W.ly_vshift;
+    HIPCHK(kh::launch_layers(e->cfg.dtype, L, st));
+    const float* fcw = W.ly_misc.as<float>() + W.ly_CP;
+    kh::launch_softmax4672(L.logits, d_policy, B, flags, st);                                   // nn.cpp:80
+    kh::launch_value_fc(L.v64, fcw, fcw + (size_t)KH_VALUE_WIDTH * 64, d_vfull, B, flags, st);   // nn.cpp:86-88
+    HIPCHK(hipGetLastError());
+    return KH_OK;
+}
+
 int forward_dispatch(kh_engine* e, const Weights& W, Slot& s, const float* d_in, int B,
                      float* d_policy, float* d_vfull, float* d_logits_out)
 {
     switch (e->cfg.dtype) {
     case KH_F32: return forward_simple(e, W, s, d_in, B, d_policy, d_vfull, d_logits_out);
     case KH_BF16:
-    case KH_F16: return forward_tower(e, W, s, d_in, B, d_policy, d_vfull, d_logits_out);
+    case KH_F16:
+        if (!W.tw_ok && W.ly_ok) return forward_layers(e, W, s, d_in, B, d_policy, d_vfull, d_logits_out);
+        return forward_tower(e, W, s, d_in, B, d_policy, d_vfull, d_logits_out);
     default: return fail(KH_ERR_INVALID, "bad dtype %d", e->cfg.dtype);
     }
 }
@@ -552,6 +650,7 @@ int kh_load_weights(kh_engine* e, const float* blob, size_t nfloats, int generat
         if ((rc = build_simple(*W, n, F, C, R))) return rc;
     } else {
         if ((rc = build_tower(*W, n, e->cfg.dtype, F, C, R))) return rc;
+        if (!W->tw_ok && (rc = build_layers(*W, n, e->cfg.dtype, F, C, R))) return rc;
     }
     std::lock_guard<std::mutex> lk(e->wmu);
     e->weights = W;                  // calls in flight keep their own reference

@@ -62,4 +62,24 @@ __host__ __device__ constexpr int tower_par_floats(int R) { return tower_par_cop
 int tower_lds_bytes(int FP, int R);
 hipError_t launch_tower(int dtype, int FP, const TowerArgs& a, int num_cus, hipStream_t s);
 
+// ---- layers_mfma.hip ----------------------------------------------------------------------
+// bf16 / f16 path for wide nets (65..256 filters): one MFMA kernel launch per layer.
+struct LayersArgs {
+    const float* in;               // [B][8][8][F] fp32 planes
+    int B, F, FP, CP, R;           // FP = F rounded up to 16, CP = filters rounded up to 64
+    unsigned short* act_in;        // T [B][64][FP]
+    unsigned short* act[3];        // T [B][64][CP]
+    unsigned short* pmid;          // T [B][64][128]
+    float* logits;                 // [B][4672]
+    float* v64;                    // [B][64]
+    const unsigned short* w;       // packed fragments of all layers (device)
+    const size_t* w_off;           // HOST array: element offset of each layer in w
+    const float* shift;            // folded shifts of all layers (device)
+    const size_t* shift_off;       // HOST array: float offset of each layer in shift
+    const float* vw;               // [CP] valueconv weight * bn scale (device)
+    float vshift;
+};
+size_t layers_lds_bytes(int Ci);
+hipError_t launch_layers(int dtype, const LayersArgs& L, hipStream_t s);
+
 }  // namespace kh

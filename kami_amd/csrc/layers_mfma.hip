@@ -1,0 +1,258 @@
+// layers_mfma.hip — bf16 / f16 forward pass for WIDE nets (65..256 filters): one MFMA kernel
+// launch per layer, activations as T [B][64][C] (channels-last) in HBM / L2.
+//
+// The whole-network kernel (tower_mfma.hip) is specialised for <= 64 filters, where a launch
+// per layer would cost more than the arithmetic.  From 128 filters up a 3x3 layer is >= 4x the
+// work (19 GFLOP per layer at 256 filters x 256 boards), launch boundaries stop mattering, the
+// activations of two boards no longer fit LDS twice, and the weights of one layer (up to 1.2 MB)
+// are better read once per 64-channel output block than streamed through every CU: so this
+// path is a plain per-layer implicit GEMM.  It covers BASELINE configs 3 and 5 (10x128, 20x256)
+// for parity; it has not been tuned against the roofline yet.
+//
+// Kernel: workgroup = 2 boards x 64 output channels.  The two boards' input images (all Ci
+// channels, zero halo, pixel stride 2*Ci + 16 bytes, row pitch 12: same conflict-free geometry as
+// the tower kernel) are staged in LDS once; each of the 4 waves computes 64 channels x 32 pixels,
+// B fragments from LDS, A fragments (pre-packed weights) straight from global memory / L2.
+#include "kh_internal.h"
+
+namespace kh {
+namespace lay {
+
+using bf16x8 = __attribute__((ext_vector_type(8))) __bf16;
+using f16x8 = __attribute__((ext_vector_type(8))) _Float16;
+using f32x16 = __attribute__((ext_vector_type(16))) float;
+using u32x4 = __attribute__((ext_vector_type(4))) unsigned;
+using u32x2 = __attribute__((ext_vector_type(2))) unsigned;
+
+constexpr int PITCH = 12;
+constexpr int NPIX = 10 * PITCH;
+
+// same lane -> pixel map as tower_mfma.hip (conflict-free ds_read_b128 groups with PITCH 12)
+__device__ __constant__ const unsigned char PIXMAP[32] = {
+    0, 1, 2, 3, 8, 9, 10, 11, 12, 13, 14, 15, 4, 5, 6, 7,
+    24, 25, 26, 27, 16, 17, 18, 19, 20, 21, 22, 23, 28, 29, 30, 31
+};
+
+template <typename T> struct Elem;
+template <> struct Elem<__bf16> {
+    using vec8 = bf16x8;
+    static __device__ __forceinline__ f32x16 mfma(vec8 a, vec8 b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0); }
+};
+template <> struct Elem<_Float16> {
+    using vec8 = f16x8;
+    static __device__ __forceinline__ f32x16 mfma(vec8 a, vec8 b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0); }
+};
+
+template <typename T> __device__ __forceinline__ unsigned short to_bits(float v)
+{
+    const T t = (T)v;
+    return __builtin_bit_cast(unsigned short, t);
+}
+template <typename T> __device__ __forceinline__ float from_bits(unsigned short u) { return (float)__builtin_bit_cast(T, u); }
+__device__ __forceinline__ float relu_keep_nan(float v) { return v < 0.0f ? 0.0f : v; }   // torch::relu semantics
+
+// fp32 planes [B][64][F] -> T [B][64][FP] (channels >= F zero).  One thread per 8-channel chunk.
+template <typename T>
+__global__ __launch_bounds__(256) void planes_to_act_kernel(const float* __restrict__ in, unsigned short* __restrict__ out,
+                                                            long npix, int F, int FP)
+{
+    const int CH = FP / 8;
+    const long total = npix * CH;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const long p = i / CH;
+        const int c0 = (int)(i % CH) * 8;
+        const float* src = in + p * F + c0;
+        unsigned short v[8];
+        for (int k = 0; k < 8; ++k) v[k] = to_bits<T>((c0 + k < F) ? src[k] : 0.0f);
+        u32x4 o;
+        o.x = v[0] | ((unsigned)v[1] << 16); o.y = v[2] | ((unsigned)v[3] << 16);
+        o.z = v[4] | ((unsigned)v[5] << 16); o.w = v[6] | ((unsigned)v[7] << 16);
+        *reinterpret_cast<u32x4*>(out + p * FP + c0) = o;
+    }
+}
+
+struct ConvArgs {
+    const unsigned short* in;     // T [B][64][Ci]
+    const unsigned short* w;      // packed fragments [Co/64][taps][Ci/16][2][64 lanes][8]
+    const float* shift;           // [Co] folded BatchNorm shift (or bias)
+    const unsigned short* skip;   // T [B][64][Co] (EPI 1) or nullptr
+    void* out;                    // T [B][64][Co] (EPI 0/1) or fp32 [B][4672] (EPI 2)
+    int B, Ci, Co;                // Ci % 16 == 0, Co % 64 == 0
+};
+
+// EPI: 0 = ReLU -> T;  1 = ReLU, + skip -> T (nn.cpp:31);  2 = raw fp32 logits, planes < 73 (nn.cpp:75-79)
+template <typename T, int TAPS, int EPI>
+__global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    using V = typename Elem<T>::vec8;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 5;
+    const int Ci = a.Ci, Co = a.Co, KS = Ci / 16;
+    const int stride = Ci * 2 + 16;
+    const int npx = (TAPS == 9) ? NPIX : 64;              // pixels per board image
+    const int board_bytes = npx * stride;
+    const int b0 = blockIdx.x * 2, cb = blockIdx.y;
+
+    // ---- stage the two boards' input in LDS
+    if (TAPS == 9) {
+        const u32x4 z = { 0, 0, 0, 0 };
+        const int per_px = stride / 16;
+        for (int i = tid; i < 2 * NPIX; i += 256) {
+            const int pp = i % NPIX, yy = pp / PITCH, xx = pp % PITCH;
+            if (yy >= 1 && yy <= 8 && xx >= 1 && xx <= 8) continue;
+            char* d = smem + (i / NPIX) * board_bytes + pp * stride;
+            for (int k = 0; k < per_px; ++k) *reinterpret_cast<u32x4*>(d + k * 16) = z;
+        }
+    }
+    {
+        const int CH = Ci / 8;
+        for (int i = tid; i < 2 * 64 * CH; i += 256) {
+            const int bb = i / (64 * CH), p = (i / CH) & 63, c = i % CH;
+            u32x4 v = { 0, 0, 0, 0 };
+            if (b0 + bb < a.B) v = *reinterpret_cast<const u32x4*>(a.in + ((size_t)(b0 + bb) * 64 + p) * Ci + c * 8);
+            const int pix = (TAPS == 9) ? ((p >> 3) + 1) * PITCH + (p & 7) + 1 : p;
+            *reinterpret_cast<u32x4*>(smem + bb * board_bytes + pix * stride + c * 16) = v;
+        }
+    }
+    __syncthreads();
+
+    // ---- this wave: board wave>>1, rows 4*(wave&1)..+3, all 64 channels of block cb
+    const int wb = wave >> 1;
+    const int lp = PIXMAP[lane & 31];
+    const int py = 4 * (wave & 1) + (lp >> 3), px = lp & 7;
+    const unsigned b_base = wb * board_bytes + ((TAPS == 9) ? (py * PITCH + px) : (py * 8 + px)) * stride + h * 16;
+    f32x16 acc[2];
+#pragma unroll
+    for (int ms = 0; ms < 2; ++ms)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const float4 s = *reinterpret_cast<const float4*>(a.shift + cb * 64 + ms * 32 + 8 * g + 4 * h);
+            acc[ms][4 * g + 0] = s.x; acc[ms][4 * g + 1] = s.y; acc[ms][4 * g + 2] = s.z; acc[ms][4 * g + 3] = s.w;
+        }
+    const unsigned short* wp = a.w + ((size_t)cb * TAPS * KS * 2) * 512 + lane * 8;     // 512 elements per fragment
+    for (int tap = 0; tap < TAPS; ++tap) {
+        const unsigned toff = (TAPS == 9) ? (unsigned)(((tap / 3) * PITCH + (tap % 3)) * stride) : 0u;
+#pragma unroll 4
+        for (int ks = 0; ks < KS; ++ks) {
+            const V b = *reinterpret_cast<const V*>(smem + b_base + toff + ks * 32);
+            const unsigned short* f = wp + ((size_t)(tap * KS + ks) * 2) * 512;
+            const V a0 = *reinterpret_cast<const V*>(f);
+            const V a1 = *reinterpret_cast<const V*>(f + 512);
+            acc[0] = Elem<T>::mfma(a0, b, acc[0]);
+            acc[1] = Elem<T>::mfma(a1, b, acc[1]);
+        }
+    }
+
+    // ---- epilogue
+    const int b = b0 + wb;
+    if (b >= a.B) return;
+    const int p = py * 8 + px;
+#pragma unroll
+    for (int ms = 0; ms < 2; ++ms)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int ch = cb * 64 + ms * 32 + 8 * g + 4 * h;
+            float v[4] = { acc[ms][4 * g], acc[ms][4 * g + 1], acc[ms][4 * g + 2], acc[ms][4 * g + 3] };
+            if (EPI == 2) {
+                float* lo = reinterpret_cast<float*>(a.out) + (size_t)b * KH_PSIZE + p * KH_POLICY_PLANES;
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                    if (ch + i < KH_POLICY_PLANES) lo[ch + i] = v[i];
+            } else {
+                const size_t o = ((size_t)b * 64 + p) * Co + ch;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) v[i] = relu_keep_nan(v[i]);
+                if (EPI == 1) {
+                    const u32x2 s = *reinterpret_cast<const u32x2*>(a.skip + o);
+                    v[0] += from_bits<T>((unsigned short)(s.x & 0xffff)); v[1] += from_bits<T>((unsigned short)(s.x >> 16));
+                    v[2] += from_bits<T>((unsigned short)(s.y & 0xffff)); v[3] += from_bits<T>((unsigned short)(s.y >> 16));
+                }
+                u32x2 r;
+                r.x = to_bits<T>(v[0]) | ((unsigned)to_bits<T>(v[1]) << 16);
+                r.y = to_bits<T>(v[2]) | ((unsigned)to_bits<T>(v[3]) << 16);
+                *reinterpret_cast<u32x2*>(reinterpret_cast<unsigned short*>(a.out) + o) = r;
+            }
+        }
+}
+
+// valueconv + vbatchnorm + relu (nn.cpp:83-85) on T activations: one thread per (board, pixel)
+template <typename T>
+__global__ __launch_bounds__(256) void value_conv_kernel(const unsigned short* __restrict__ x, const float* __restrict__ vw,
+                                                         float vshift, float* __restrict__ v64, long npix, int C)
+{
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < npix; i += (long)gridDim.x * blockDim.x) {
+        const unsigned short* xp = x + i * C;
+        float s = 0.0f;
+        for (int c = 0; c < C; c += 8) {
+            const u32x4 u = *reinterpret_cast<const u32x4*>(xp + c);
+            const unsigned w[4] = { u.x, u.y, u.z, u.w };
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                s = fmaf(from_bits<T>((unsigned short)(w[k] & 0xffff)), vw[c + 2 * k], s);
+                s = fmaf(from_bits<T>((unsigned short)(w[k] >> 16)), vw[c + 2 * k + 1], s);
+            }
+        }
+        v64[i] = relu_keep_nan(s + vshift);
+    }
+}
+
+template <typename T, int TAPS, int EPI> static hipError_t launch_conv(const ConvArgs& a, hipStream_t s)
+{
+    const int stride = a.Ci * 2 + 16;
+    const int lds = 2 * ((TAPS == 9) ? NPIX : 64) * stride;
+    static bool attr_done = false;
+    if (!attr_done) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_mfma_kernel<T, TAPS, EPI>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) return e;
+        attr_done = true;
+    }
+    hipLaunchKernelGGL((conv_mfma_kernel<T, TAPS, EPI>), dim3((a.B + 1) / 2, a.Co / 64), dim3(256), lds, s, a);
+    return hipGetLastError();
+}
+
+template <typename T> static hipError_t run(const LayersArgs& L, hipStream_t s)
+{
+    const long npix = (long)L.B * 64;
+    int blocks = (int)((npix * (L.FP / 8) + 255) / 256);
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(planes_to_act_kernel<T>, dim3(blocks), dim3(256), 0, s, L.in, L.act_in, npix, L.F, L.FP);
+    unsigned short *x = L.act[0], *t = L.act[1], *u = L.act[2];
+    hipError_t e;
+    size_t li = 0;
+    auto layer = [&](int idx) { return L.w + L.w_off[idx]; };
+    auto shift = [&](int idx) { return L.shift + L.shift_off[idx]; };
+    ConvArgs a;
+    a.B = L.B;
+    // stem                                                                  nn.cpp:62-65
+    a.in = L.act_in; a.w = layer(li); a.shift = shift(li); a.skip = nullptr; a.out = x; a.Ci = L.FP; a.Co = L.CP; ++li;
+    if ((e = launch_conv<T, 9, 0>(a, s)) != hipSuccess) return e;
+    for (int r = 0; r < L.R; ++r) {                                       // nn.cpp:26-34
+        a.in = x; a.w = layer(li); a.shift = shift(li); a.skip = nullptr; a.out = t; a.Ci = L.CP; a.Co = L.CP; ++li;
+        if ((e = launch_conv<T, 9, 0>(a, s)) != hipSuccess) return e;
+        a.in = t; a.w = layer(li); a.shift = shift(li); a.skip = x; a.out = u; ++li;
+        if ((e = launch_conv<T, 9, 1>(a, s)) != hipSuccess) return e;
+        unsigned short* tmp = x; x = u; u = tmp;
+    }
+    // policy head                                                           nn.cpp:72-79
+    a.in = x; a.w = layer(li); a.shift = shift(li); a.skip = nullptr; a.out = L.pmid; a.Ci = L.CP; a.Co = KH_POLICY_MID; ++li;
+    if ((e = launch_conv<T, 1, 0>(a, s)) != hipSuccess) return e;
+    a.in = L.pmid; a.w = layer(li); a.shift = shift(li); a.out = L.logits; a.Ci = KH_POLICY_MID; a.Co = 128; ++li;
+    if ((e = launch_conv<T, 1, 2>(a, s)) != hipSuccess) return e;
+    // value head, first half                                                nn.cpp:83-85
+    int vb = (int)((npix + 255) / 256);
+    if (vb > 4096) vb = 4096;
+    hipLaunchKernelGGL(value_conv_kernel<T>, dim3(vb), dim3(256), 0, s, x, L.vw, L.vshift, L.v64, npix, L.CP);
+    return hipGetLastError();
+}
+
+}  // namespace lay
+
+size_t layers_lds_bytes(int Ci) { return (size_t)2 * lay::NPIX * (Ci * 2 + 16); }
+
+hipError_t launch_layers(int dtype, const LayersArgs& L, hipStream_t s)
+{
+    return dtype == KH_BF16 ? lay::run<__bf16>(L, s) : lay::run<_Float16>(L, s);
+}
+
+}  // namespace kh

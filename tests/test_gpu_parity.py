@@ -141,9 +141,31 @@ def test_mfma_nan_guard():
     assert ei.value.status == L.KH_ERR_NAN_POLICY
 
 
+@pytest.mark.parametrize("dtype", ["f16", "bf16"])
+@pytest.mark.parametrize("F,C,R,B", [(119, 128, 3, 9), (30, 256, 2, 5), (30, 96, 1, 4), (200, 64, 1, 3)])
+def test_forward_wide_nets_vs_oracle(dtype, F, C, R, B):
+    """Nets the whole-network kernel does not cover (filters > 64 or features > 128) run the
+    per-layer MFMA path (layers_mfma.hip): BASELINE configs 3 and 5 shapes, small batch."""
+    blob = W.random_weights(F, C, R, seed=F + C + R, peaky=20.0)
+    x = np.random.default_rng(B).random((B, 8, 8, F), dtype=np.float32)
+    nn = NN(8, 8, F, 4672, filters=C, residuals=R, dtype=dtype)
+    nn.load_weights(blob, 1)
+    p, vf, lg = nn.infer_full(x)
+    op, ovf, olg = ko.forward(blob, F, C, R, x)
+    tol = TOL[dtype]
+    np.testing.assert_allclose(lg, olg, atol=tol["logp"], rtol=0)
+    np.testing.assert_allclose(np.log(p), np.log(op), atol=tol["logp"], rtol=0)
+    np.testing.assert_allclose(vf, ovf, atol=tol["value"], rtol=0)
+    # NaN guard on this path too
+    xb = x.copy(); xb[B - 1, 0, 0, 0] = np.nan
+    with pytest.raises(KamiError) as ei:
+        nn.infer(xb)
+    assert ei.value.status == L.KH_ERR_NAN_POLICY
+
+
 def test_mfma_unsupported_config_fails_loudly():
-    nn = NN(8, 8, 30, 4672, filters=128, residuals=1, dtype="bf16")
-    nn.load_weights(W.random_weights(30, 128, 1, seed=1), 1)
+    nn = NN(8, 8, 30, 4672, filters=320, residuals=1, dtype="bf16")
+    nn.load_weights(W.random_weights(30, 320, 1, seed=1), 1)
     with pytest.raises(KamiError) as ei:
         nn.infer(np.zeros((1, 8, 8, 30), np.float32))
     assert ei.value.status == L.KH_ERR_INVALID
