@@ -196,6 +196,180 @@ __global__ __launch_bounds__(256) void value_conv_kernel(const unsigned short* _
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// fp32 on the matrix cores: v_mfma_f32_32x32x2_f32 is an exact f32 fmaf chain (1/16 of the bf16
+// rate, 157 TFLOP/s peak).  Same structure as conv_mfma_kernel with fp32 activations [B][64][C]:
+// per 8 input channels one ds_read_b128 (lane (pixel r, h) holds channels 8j + 4h + 0..3), two
+// 16-byte weight loads (lane (co r, h) holds W[co][8j + 4h + 0..3]) and 8 MFMAs — MFMA i pairs
+// element i of both, i.e. k = h <-> channel 8j + 4h + i on either side.
+using f32x4v = __attribute__((ext_vector_type(4))) float;
+
+struct ConvArgsF32 {
+    const float* in;      // [B][64][Ci]
+    const float* w;       // packed [Co/64][taps][Ci/8][2][64 lanes][4]
+    const float* shift;   // [Co]
+    const float* skip;    // [B][64][Co] or nullptr
+    float* out;           // [B][64][Co] (EPI 0/1) or [B][4672] (EPI 2)
+    int B, Ci, Co;        // Ci % 8 == 0, Co % 64 == 0
+};
+
+template <int TAPS, int EPI>
+__global__ __launch_bounds__(256) void conv_f32_kernel(ConvArgsF32 a)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 5;
+    const int Ci = a.Ci, Co = a.Co, KJ = Ci / 8;
+    const int stride = Ci * 4 + 16;                       // (Ci/4 + 1) 16-byte slots: odd -> conflict-free
+    const int npx = (TAPS == 9) ? NPIX : 64;
+    const int board_bytes = npx * stride;
+    const int b0 = blockIdx.x * 2, cb = blockIdx.y;
+    if (TAPS == 9) {
+        const u32x4 z = { 0, 0, 0, 0 };
+        const int per_px = stride / 16;
+        for (int i = tid; i < 2 * NPIX; i += 256) {
+            const int pp = i % NPIX, yy = pp / PITCH, xx = pp % PITCH;
+            if (yy >= 1 && yy <= 8 && xx >= 1 && xx <= 8) continue;
+            char* d = smem + (i / NPIX) * board_bytes + pp * stride;
+            for (int k = 0; k < per_px; ++k) *reinterpret_cast<u32x4*>(d + k * 16) = z;
+        }
+    }
+    {
+        const int CH = Ci / 4;
+        for (int i = tid; i < 2 * 64 * CH; i += 256) {
+            const int bb = i / (64 * CH), p = (i / CH) & 63, c = i % CH;
+            u32x4 v = { 0, 0, 0, 0 };
+            if (b0 + bb < a.B) v = *reinterpret_cast<const u32x4*>(a.in + ((size_t)(b0 + bb) * 64 + p) * Ci + c * 4);
+            const int pix = (TAPS == 9) ? ((p >> 3) + 1) * PITCH + (p & 7) + 1 : p;
+            *reinterpret_cast<u32x4*>(smem + bb * board_bytes + pix * stride + c * 16) = v;
+        }
+    }
+    __syncthreads();
+    const int wb = wave >> 1;
+    const int lp = PIXMAP[lane & 31];
+    const int py = 4 * (wave & 1) + (lp >> 3), px = lp & 7;
+    const unsigned b_base = wb * board_bytes + ((TAPS == 9) ? (py * PITCH + px) : (py * 8 + px)) * stride + h * 16;
+    f32x16 acc[2];
+#pragma unroll
+    for (int ms = 0; ms < 2; ++ms)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const float4 s = *reinterpret_cast<const float4*>(a.shift + cb * 64 + ms * 32 + 8 * g + 4 * h);
+            acc[ms][4 * g + 0] = s.x; acc[ms][4 * g + 1] = s.y; acc[ms][4 * g + 2] = s.z; acc[ms][4 * g + 3] = s.w;
+        }
+    const float* wp = a.w + ((size_t)cb * TAPS * KJ * 2) * 256 + lane * 4;     // 256 floats per fragment
+    for (int tap = 0; tap < TAPS; ++tap) {
+        const unsigned toff = (TAPS == 9) ? (unsigned)(((tap / 3) * PITCH + (tap % 3)) * stride) : 0u;
+#pragma unroll 2
+        for (int j = 0; j < KJ; ++j) {
+            const f32x4v b = *reinterpret_cast<const f32x4v*>(smem + b_base + toff + j * 32);
+            const float* f = wp + ((size_t)(tap * KJ + j) * 2) * 256;
+            const f32x4v a0 = *reinterpret_cast<const f32x4v*>(f);
+            const f32x4v a1 = *reinterpret_cast<const f32x4v*>(f + 256);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[i], b[i], acc[0], 0, 0, 0);
+                acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[i], b[i], acc[1], 0, 0, 0);
+            }
+        }
+    }
+    const int b = b0 + wb;
+    if (b >= a.B) return;
+    const int p = py * 8 + px;
+#pragma unroll
+    for (int ms = 0; ms < 2; ++ms)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int ch = cb * 64 + ms * 32 + 8 * g + 4 * h;
+            float v[4] = { acc[ms][4 * g], acc[ms][4 * g + 1], acc[ms][4 * g + 2], acc[ms][4 * g + 3] };
+            if (EPI == 2) {
+                float* lo = a.out + (size_t)b * KH_PSIZE + p * KH_POLICY_PLANES;
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                    if (ch + i < KH_POLICY_PLANES) lo[ch + i] = v[i];
+            } else {
+                const size_t o = ((size_t)b * 64 + p) * Co + ch;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) v[i] = relu_keep_nan(v[i]);
+                if (EPI == 1) {
+                    const float4 s = *reinterpret_cast<const float4*>(a.skip + o);
+                    v[0] += s.x; v[1] += s.y; v[2] += s.z; v[3] += s.w;
+                }
+                *reinterpret_cast<float4*>(a.out + o) = make_float4(v[0], v[1], v[2], v[3]);
+            }
+        }
+}
+
+// fp32 planes [B][64][F] -> [B][64][FP] zero-padded (FP = F rounded up to 8)
+__global__ __launch_bounds__(256) void pad_planes_kernel(const float* __restrict__ in, float* __restrict__ out, long npix, int F, int FP)
+{
+    const long total = npix * FP;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const long p = i / FP;
+        const int c = (int)(i % FP);
+        out[i] = c < F ? in[p * F + c] : 0.0f;
+    }
+}
+
+__global__ __launch_bounds__(256) void value_conv_f32_kernel(const float* __restrict__ x, const float* __restrict__ vw,
+                                                             float vshift, float* __restrict__ v64, long npix, int C)
+{
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < npix; i += (long)gridDim.x * blockDim.x) {
+        const float* xp = x + i * C;
+        float s = 0.0f;
+        for (int c = 0; c < C; ++c) s = fmaf(xp[c], vw[c], s);
+        v64[i] = relu_keep_nan(s + vshift);
+    }
+}
+
+template <int TAPS, int EPI> static hipError_t launch_conv_f32(const ConvArgsF32& a, hipStream_t s)
+{
+    const int lds = 2 * ((TAPS == 9) ? NPIX : 64) * (a.Ci * 4 + 16);
+    static bool attr_done = false;
+    if (!attr_done) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_f32_kernel<TAPS, EPI>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) return e;
+        attr_done = true;
+    }
+    hipLaunchKernelGGL((conv_f32_kernel<TAPS, EPI>), dim3((a.B + 1) / 2, a.Co / 64), dim3(256), lds, s, a);
+    return hipGetLastError();
+}
+
+static hipError_t run_f32(const LayersArgs& L, hipStream_t s)
+{
+    const long npix = (long)L.B * 64;
+    const float* in = L.in;
+    if (L.FP != L.F) {
+        int blocks = (int)((npix * L.FP + 255) / 256);
+        if (blocks > 4096) blocks = 4096;
+        hipLaunchKernelGGL(pad_planes_kernel, dim3(blocks), dim3(256), 0, s, L.in, reinterpret_cast<float*>(L.act_in), npix, L.F, L.FP);
+        in = reinterpret_cast<const float*>(L.act_in);
+    }
+    float *x = reinterpret_cast<float*>(L.act[0]), *t = reinterpret_cast<float*>(L.act[1]), *u = reinterpret_cast<float*>(L.act[2]);
+    const float* wbase = reinterpret_cast<const float*>(L.w);
+    hipError_t e;
+    size_t li = 0;
+    ConvArgsF32 a;
+    a.B = L.B;
+    a.in = in; a.w = wbase + L.w_off[li]; a.shift = L.shift + L.shift_off[li]; a.skip = nullptr; a.out = x; a.Ci = L.FP; a.Co = L.CP; ++li;
+    if ((e = launch_conv_f32<9, 0>(a, s)) != hipSuccess) return e;
+    for (int r = 0; r < L.R; ++r) {
+        a.in = x; a.w = wbase + L.w_off[li]; a.shift = L.shift + L.shift_off[li]; a.skip = nullptr; a.out = t; a.Ci = L.CP; a.Co = L.CP; ++li;
+        if ((e = launch_conv_f32<9, 0>(a, s)) != hipSuccess) return e;
+        a.in = t; a.w = wbase + L.w_off[li]; a.shift = L.shift + L.shift_off[li]; a.skip = x; a.out = u; ++li;
+        if ((e = launch_conv_f32<9, 1>(a, s)) != hipSuccess) return e;
+        float* tmp = x; x = u; u = tmp;
+    }
+    a.in = x; a.w = wbase + L.w_off[li]; a.shift = L.shift + L.shift_off[li]; a.skip = nullptr; a.out = reinterpret_cast<float*>(L.pmid); a.Ci = L.CP; a.Co = KH_POLICY_MID; ++li;
+    if ((e = launch_conv_f32<1, 0>(a, s)) != hipSuccess) return e;
+    a.in = reinterpret_cast<const float*>(L.pmid); a.w = wbase + L.w_off[li]; a.shift = L.shift + L.shift_off[li]; a.out = L.logits; a.Ci = KH_POLICY_MID; a.Co = 128; ++li;
+    if ((e = launch_conv_f32<1, 2>(a, s)) != hipSuccess) return e;
+    int vb = (int)((npix + 255) / 256);
+    if (vb > 4096) vb = 4096;
+    hipLaunchKernelGGL(value_conv_f32_kernel, dim3(vb), dim3(256), 0, s, x, L.vw, L.vshift, L.v64, npix, L.CP);
+    return hipGetLastError();
+}
+
 template <typename T, int TAPS, int EPI> static hipError_t launch_conv(const ConvArgs& a, hipStream_t s)
 {
     const int stride = a.Ci * 2 + 16;
@@ -252,6 +426,7 @@ size_t layers_lds_bytes(int Ci) { return (size_t)2 * lay::NPIX * (Ci * 2 + 16); 
 
 hipError_t launch_layers(int dtype, const LayersArgs& L, hipStream_t s)
 {
+    if (dtype == KH_F32) return lay::run_f32(L, s);
     return dtype == KH_BF16 ? lay::run<__bf16>(L, s) : lay::run<_Float16>(L, s);
 }
 

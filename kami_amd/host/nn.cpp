@@ -98,10 +98,11 @@ NN::NN(int width, int height, int features, int psize, bool force_cpu) :
     filters = options::getInt("filters", 256);          // nn.cpp:42
     residuals = options::getInt("residuals", 2);        // nn.cpp:43
     int dtype = dtype_from_options();
-    if (dtype != KH_F32 && (filters > 64 || features > 128)) {
-        // the MFMA tower kernel covers filters <= 64 today; wider nets run the exact-order fp32 kernels
+    if (dtype != KH_F32 && (filters > 256 || features > 256)) {
+        // bf16/f16: whole-network kernel up to 64 filters, per-layer MFMA kernels up to 256; beyond
+        // that only the plain fp32 kernels apply
         std::cerr << "kami::NN: " << filters << " filters / " << features
-                  << " features is outside the bf16/f16 kernel's range, using the fp32 HIP path\n";
+                  << " features is outside the bf16/f16 kernels' range, using the fp32 HIP path\n";
         dtype = KH_F32;
     }
     create(dtype);

@@ -171,6 +171,20 @@ def test_mfma_unsupported_config_fails_loudly():
     assert ei.value.status == L.KH_ERR_INVALID
 
 
+def test_forward_f32_exact_order_kernels(net_fixture, monkeypatch):
+    """KAMI_F32_SIMPLE=1: the plain VALU kernels in the oracle's accumulation order (the anchor the
+    exact-f32 MFMA path is cross-checked against)."""
+    monkeypatch.setenv("KAMI_F32_SIMPLE", "1")
+    nn = make_nn(net_fixture, "f32")
+    check_forward(nn, net_fixture, "f32")
+    monkeypatch.delenv("KAMI_F32_SIMPLE")
+    nn2 = make_nn(net_fixture, "f32")
+    p1, v1, l1 = nn.infer_full(net_fixture["x"])
+    p2, v2, l2 = nn2.infer_full(net_fixture["x"])
+    np.testing.assert_allclose(l1, l2, atol=1e-4, rtol=0)     # two fp32 summation orders
+    np.testing.assert_allclose(v1, v2, atol=1e-5, rtol=0)
+
+
 def test_infer_reference_value_copyout(net_fixture):
     """value[i] = flattened [B,256] tensor element i (nn.cpp:186)."""
     d = net_fixture
