@@ -96,8 +96,14 @@ def main():
     rank, local_rank, world = kd.env_rank()
     if not torch.cuda.is_available():
         sys.exit("bench.py needs a GPU (the engine has no CPU path)")
-    torch.cuda.set_device(local_rank)
-    dist = kd.init("nccl")          # RCCL; only the barrier and the max-over-ranks use it
+    # one rank per GPU (the driver's multi-GPU run); KAMI_DIST_BACKEND=gloo lets two ranks share
+    # one GPU to rehearse the N > 1 control flow on a single-GPU box (RCCL refuses duplicate devices)
+    backend = os.environ.get("KAMI_DIST_BACKEND", "nccl")
+    dev_index = local_rank % max(1, torch.cuda.device_count())
+    local_rank = dev_index
+    torch.cuda.set_device(dev_index)
+    dist = kd.init(backend)         # RCCL; only the barrier and the max-over-ranks use it
+    red_dev = "cuda" if backend == "nccl" else "cpu"
 
     F, Cc, R, B = a.features, a.filters, a.residuals, a.batch
     nn = NN(8, 8, F, 4672, filters=Cc, residuals=R, dtype=a.dtype, device=local_rank)
@@ -131,7 +137,7 @@ def main():
     torch.cuda.synchronize()
     barrier()
     dt = time.perf_counter() - t0
-    dt = kd.max_over_ranks(dist, dt, device="cuda")
+    dt = kd.max_over_ranks(dist, dt, device=red_dev)
     assert bool(torch.isfinite(policy).all()) and abs(float(policy[0].sum()) - 1.0) < 1e-2
 
     # roofline of the dominant kernel (the forward pass), HIP events on the engine's own stream
