@@ -60,12 +60,13 @@ __global__ __launch_bounds__(64 * ENC_WAVES) void encode_f32_kernel(const kh_boa
         }
         __syncthreads();
         if (b < n) {
-            const float4* src = reinterpret_cast<const float4*>(tile);
-            float4* out = reinterpret_cast<float4*>(planes + (size_t)b * ENC_TILE);
+            using f4 = float __attribute__((ext_vector_type(4)));
+            const f4* src = reinterpret_cast<const f4*>(tile);
+            f4* out = reinterpret_cast<f4*>(planes + (size_t)b * ENC_TILE);
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
                 const int q = lane + 64 * j;
-                if (q < ENC_TILE / 4) out[q] = src[q];
+                if (q < ENC_TILE / 4) __builtin_nontemporal_store(src[q], &out[q]);   // write-once stream
             }
         }
         __syncthreads();
