@@ -32,7 +32,7 @@ def cpu_baseline(F, Cc, R, batch):
     except AttributeError:
         cores = os.cpu_count() or 1
     cores = max(1, min(cores, int(os.environ.get("KAMI_CPU_CORES", "16"))))
-    iters = 8
+    iters = 40      # ~1 s of wall time on 16 threads = ~16 CPU-seconds, the bounded sample
     if os.path.exists(ref):
         try:
             out = subprocess.run([ref, "bench", str(F), str(Cc), str(R), str(batch), str(iters), str(cores)],

@@ -578,7 +578,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                     float4 o;
                     o.x = v[k].x * inv; o.y = v[k].y * inv; o.z = v[k].z * inv; o.w = v[k].w * inv;
                     nan |= (o.x != o.x) | (o.y != o.y) | (o.z != o.z) | (o.w != o.w);
-                    if (tt + 128 * k < NQ) po[tt + 128 * k] = o;
+                    if (tt + 128 * k < NQ) {        // write-once stream: non-temporal
+                        using f4 = float __attribute__((ext_vector_type(4)));
+                        const f4 ov = { o.x, o.y, o.z, o.w };
+                        __builtin_nontemporal_store(ov, reinterpret_cast<f4*>(po) + tt + 128 * k);
+                    }
                 }
             }
             if (__any(nan) && lane == 0) atomicOr(&a.flags[0], 1);
