@@ -57,3 +57,23 @@ def max_over_ranks(dist, value: float, device: str = "cpu") -> float:
     t = torch.tensor([value], dtype=torch.float64, device=device)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return float(t.item())
+
+
+def broadcast_weights(dist, blob, generation: int, src: int = 0, device: str = "cpu"):
+    """New parameters from the trainer rank to every evaluator rank: the multi-process counterpart
+    of `model->read(path)` after a candidate is accepted (selfplay.cpp:282-283).  One collective
+    of the whole blob (2 MB for 6x64, 95 MB for 20x256) plus the generation; RCCL over xGMI with
+    device tensors, gloo on CPU.  Returns (blob, generation) on every rank."""
+    import numpy as np
+    import torch
+    if dist is None:
+        return np.ascontiguousarray(blob, dtype=np.float32), generation
+    meta = torch.tensor([generation, 0 if blob is None else int(np.asarray(blob).size)], dtype=torch.int64, device=device)
+    dist.broadcast(meta, src=src)
+    n = int(meta[1].item())
+    if dist.get_rank() == src:
+        t = torch.from_numpy(np.ascontiguousarray(blob, dtype=np.float32)).to(device)
+    else:
+        t = torch.empty(n, dtype=torch.float32, device=device)
+    dist.broadcast(t, src=src)
+    return t.cpu().numpy(), int(meta[0].item())

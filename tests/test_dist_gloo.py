@@ -57,3 +57,8 @@ def test_two_rank_gloo(tmp_path):
     assert res[0]["inserted"] == 4 and res[0]["total"] == 7 and res[1]["inserted"] == 0
     assert res[0]["first_col"] == [0, 1, 2, 100, 101, 102, 103]
     assert res[0]["results"] == [0, 1, 2, 0, 1, 2, 3]
+    # weight broadcast (selfplay.cpp:282-283 across processes): every rank ends with rank 0's blob
+    from kami_amd import weights as W
+    ref = W.random_weights(30, 8, 1, seed=77)
+    assert all(r["wgen"] == 41 and r["wn"] == ref.size for r in res)
+    assert all(abs(r["wsum"] - float(ref.astype(np.float64).sum())) < 1e-9 for r in res)

@@ -377,3 +377,54 @@ def test_reference_programs_on_the_cpp_mirror(tmp_path):
     assert r.returncode == 0, r.stderr
     assert "mismatch" not in r.stderr and "mismatch" not in r.stdout
     assert "Saved model to" in r.stdout
+
+
+# ------------------------------------------------------------------------------ full-size properties
+def test_full_size_properties_headline_config():
+    """BASELINE configs[1] at its full size (512 x 119x8x8, 6x64), where the oracle is too slow to
+    be the checker for every row: size-independent properties instead."""
+    F, C, R, B = 119, 64, 6, 512
+    blob = W.random_weights(F, C, R, seed=20240607, peaky=20.0)
+    x = np.random.default_rng(1).random((B, 8, 8, F), dtype=np.float32)
+    out = {}
+    for dtype in ("bf16", "f16", "f32"):
+        nn = NN(8, 8, F, 4672, filters=C, residuals=R, dtype=dtype)
+        nn.load_weights(blob, 1)
+        p, vf, _ = nn.infer_full(x, want_logits=False)
+        out[dtype] = (p, vf)
+        assert np.isfinite(p).all() and (p >= 0).all()
+        np.testing.assert_allclose(p.sum(1, dtype=np.float64), 1.0, atol=2e-5)       # softmax rows
+        assert np.abs(vf).max() <= 1.0                                               # tanh range
+        # batching invariance: the two halves evaluated separately give the same bits
+        p2, vf2, _ = nn.infer_full(x[256:], want_logits=False)
+        assert np.array_equal(p2, p[256:]) and np.array_equal(vf2, vf[256:])
+        # permutation equivariance: rows follow their inputs
+        perm = np.random.default_rng(2).permutation(B)
+        p3, vf3, _ = nn.infer_full(x[perm], want_logits=False)
+        assert np.array_equal(p3, p[perm]) and np.array_equal(vf3, vf[perm])
+    # cross-precision agreement within the stated tolerances (f32 = exact MFMA path as the anchor)
+    for dtype in ("bf16", "f16"):
+        np.testing.assert_allclose(np.log(out[dtype][0]), np.log(out["f32"][0]), atol=TOL[dtype]["logp"], rtol=0)
+        np.testing.assert_allclose(out[dtype][1], out["f32"][1], atol=TOL[dtype]["value"], rtol=0)
+    # and a sample of rows against the oracle
+    rows = [0, 1, 255, 256, 511]
+    op, ovf, _ = ko.forward(blob, F, C, R, x[rows])
+    np.testing.assert_allclose(np.log(out["f32"][0][rows]), np.log(op), atol=TOL["f32"]["logp"], rtol=0)
+    np.testing.assert_allclose(out["f32"][1][rows], ovf, atol=TOL["f32"]["value"], rtol=0)
+
+
+def test_encode_full_size_properties():
+    """2^20 positions: structural invariants of Env::observe's output (env.h:202-262)."""
+    n = 1 << 20
+    boards = random_boards(n, seed=5)
+    nn = NN(filters=8, residuals=0)
+    planes = nn.encode(boards).reshape(n, 64, 30)
+    assert np.array_equal(planes[:, :, :18], np.broadcast_to(planes[:, :1, :18], (n, 64, 18)))   # header broadcast (Q5)
+    occ = (boards["color_occ"][:, 0] | boards["color_occ"][:, 1])
+    typed = np.zeros(n, np.uint64)
+    for t in range(6):
+        typed |= boards["piece_occ"][:, t]
+    npieces = np.array([bin(int(v)).count("1") for v in (occ & typed)[:4096]])
+    assert np.array_equal(planes[:4096, :, 18:].sum((1, 2)).astype(int), npieces)               # one plane bit per piece
+    assert set(np.unique(planes[:, 0, 14:18])) <= {0.0, 1.0, 2.0, 4.0, 8.0}                     # raw castle bits (Q2)
+    assert np.array_equal(planes[:, 0, 0], (boards["ply"] & 1).astype(np.float32))
