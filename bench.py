@@ -59,6 +59,14 @@ def cpu_baseline(F, Cc, R, batch):
             "kind": "port", "sample": f"one oracle forward over {n} boards of 8x8x{F}, {R}x{Cc} net (OpenMP)"}
 
 
+def baseline_metric():
+    """The metric string of BASELINE.json (the file travels with the repo)."""
+    try:
+        return json.load(open(os.path.join(ROOT, "BASELINE.json")))["metric"]
+    except Exception:
+        return "NN leaf-evals/sec at batch 512 (119\u00d78\u00d78 planes), 1/2/4/8 MI355X"
+
+
 def measured_traffic(F, Cc, R, B, dtype):
     """HBM bytes per launch of the forward kernel from the PMC passes kept under profiles/
     (FETCH_SIZE / WRITE_SIZE, separate rocprofv3 --pmc runs, gfx950 corrections applied as
@@ -152,7 +160,7 @@ def main():
 
     if rank == 0:
         out = {
-            "metric": "NN leaf-evals/sec at batch 512 (119x8x8 planes)",
+            "metric": baseline_metric(),
             "value": round(world * B * a.steps / dt, 1),
             "unit": "leaf-evals/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
