@@ -643,7 +643,7 @@ hipError_t launch_tower(int dtype, int FP, const TowerArgs& a, int num_cus, hipS
 {
     const int ngroups = (a.B + TW_NB - 1) / TW_NB;
     const int grid = ngroups < num_cus ? ngroups : num_cus;      // one workgroup per CU (LDS-bound residency)
-    static const int dbg = getenv("KAMI_TOWER_DBG") ? atoi(getenv("KAMI_TOWER_DBG")) : 0;   // timing experiments
+    const int dbg = getenv("KAMI_TOWER_DBG") ? atoi(getenv("KAMI_TOWER_DBG")) : 0;   // timing experiments (read per launch: in-process A/B, tools/ab_bench.py)
     static bool said = false;
     if (dbg && !said) { fprintf(stderr, "[kamihip] KAMI_TOWER_DBG=%d (timing experiment: results are WRONG) dtype=%d FP=%d\n", dbg, dtype, FP); said = true; }
     if (dbg && dtype == KH_BF16 && FP == 128) {
