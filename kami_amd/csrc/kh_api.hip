@@ -199,7 +199,8 @@ void pack_layer_f32(std::vector<float>& out, const float* w, const float* scale,
 int build_layers(Weights& W, const HostNet& n, int dtype, int F, int C, int R)
 {
     const bool f32 = dtype == KH_F32;
-    const int FP = f32 ? (F + 7) / 8 * 8 : (F + 15) / 16 * 16, CP = (C + 63) / 64 * 64;
+    // bf16/f16: input channels in multiples of 64 (an 8 KB weight chunk = 4 k-steps of one tap)
+    const int FP = f32 ? (F + 7) / 8 * 8 : (F + 63) / 64 * 64, CP = (C + 63) / 64 * 64;
     // LDS image of two boards: 2 x 120 x (Ci * elem + 16) bytes must fit 160 KB
     if (f32 ? (CP > 128 || FP > 128) : (CP > 256 || FP > 256)) return KH_OK;      // not covered: ly_ok stays false
     std::vector<uint16_t> w;

@@ -80,18 +80,48 @@ struct ConvArgs {
     int B, Ci, Co;                // Ci % 16 == 0, Co % 64 == 0
 };
 
+// ---- weight stream of one (layer, 64-channel block): 8 KB chunks (4 k-steps x 2 row tiles) through a
+// 4-slot LDS ring by LDS-DMA, exactly the tower kernel's protocol (tower_mfma.hip: pipe_step) with
+// D = 4: the 4 waves of a workgroup would otherwise each pull the same fragments through the
+// vector L1 (128 B/clk wanted, 64 available).  The ring sits at LDS offset 0 (M0's 16-bit field).
+constexpr int RD = 4;
+constexpr int CHUNKB = 8192;
+constexpr int LDS_IMG = RD * CHUNKB;
+
+__device__ __forceinline__ void ring_issue(const char* stream, int nch, int c, int wave, int lane)
+{
+    const int cs = c < nch ? c : nch - 1;                  // past the end: re-fetch the last chunk into a
+    const char* sbase = stream + (size_t)cs * CHUNKB + wave * 2048;   // free slot (keeps the vmcnt count constant)
+    const unsigned dst = (unsigned)((c % RD) * CHUNKB + wave * 2048);
+    const unsigned voff = lane * 16;
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\t"
+                 "global_load_lds_dwordx4 %1, %2\n\tglobal_load_lds_dwordx4 %1, %2 offset:1024\n\t"
+                 "s_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(voff), "s"(sbase), "s"(dst) : "memory");
+}
+
 // EPI: 0 = ReLU -> T;  1 = ReLU, + skip -> T (nn.cpp:31);  2 = raw fp32 logits, planes < 73 (nn.cpp:75-79)
 template <typename T, int TAPS, int EPI>
-__global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs a)
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void conv_mfma_kernel(ConvArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     using V = typename Elem<T>::vec8;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 5;
-    const int Ci = a.Ci, Co = a.Co, KS = Ci / 16;
+    const int tid = threadIdx.x, lane = tid & 63, h = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int Ci = a.Ci, Co = a.Co, KS = Ci / 16;          // Ci % 64 == 0: a chunk never straddles taps
     const int stride = Ci * 2 + 16;
     const int npx = (TAPS == 9) ? NPIX : 64;              // pixels per board image
     const int board_bytes = npx * stride;
     const int b0 = blockIdx.x * 2, cb = blockIdx.y;
+    const int CPT = KS / 4;                                // chunks per tap
+    const int NCH = TAPS * CPT;
+    const char* stream = reinterpret_cast<const char*>(a.w) + (size_t)cb * NCH * CHUNKB;
+    char* img = smem + LDS_IMG;
+
+    // weight stream first: the ring fills while the boards are staged
+#pragma unroll
+    for (int i = 0; i < RD - 1; ++i) ring_issue(stream, NCH, i, wave, lane);
 
     // ---- stage the two boards' input in LDS
     if (TAPS == 9) {
@@ -100,27 +130,38 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs a)
         for (int i = tid; i < 2 * NPIX; i += 256) {
             const int pp = i % NPIX, yy = pp / PITCH, xx = pp % PITCH;
             if (yy >= 1 && yy <= 8 && xx >= 1 && xx <= 8) continue;
-            char* d = smem + (i / NPIX) * board_bytes + pp * stride;
+            char* d = img + (i / NPIX) * board_bytes + pp * stride;
             for (int k = 0; k < per_px; ++k) *reinterpret_cast<u32x4*>(d + k * 16) = z;
         }
     }
     {
+        // 4 independent 16-byte loads in flight per thread, then their LDS writes (Ci % 64 == 0, so
+        // the item count 2*64*Ci/8 is a multiple of 4*256)
         const int CH = Ci / 8;
-        for (int i = tid; i < 2 * 64 * CH; i += 256) {
-            const int bb = i / (64 * CH), p = (i / CH) & 63, c = i % CH;
-            u32x4 v = { 0, 0, 0, 0 };
-            if (b0 + bb < a.B) v = *reinterpret_cast<const u32x4*>(a.in + ((size_t)(b0 + bb) * 64 + p) * Ci + c * 8);
-            const int pix = (TAPS == 9) ? ((p >> 3) + 1) * PITCH + (p & 7) + 1 : p;
-            *reinterpret_cast<u32x4*>(smem + bb * board_bytes + pix * stride + c * 16) = v;
+        for (int i0 = tid; i0 < 2 * 64 * CH; i0 += 4 * 256) {
+            u32x4 v[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int i = i0 + u * 256;
+                const int bb = i / (64 * CH), p = (i / CH) & 63, c = i % CH;
+                v[u] = u32x4{ 0, 0, 0, 0 };
+                if (b0 + bb < a.B) v[u] = *reinterpret_cast<const u32x4*>(a.in + ((size_t)(b0 + bb) * 64 + p) * Ci + c * 8);
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int i = i0 + u * 256;
+                const int bb = i / (64 * CH), p = (i / CH) & 63, c = i % CH;
+                const int pix = (TAPS == 9) ? ((p >> 3) + 1) * PITCH + (p & 7) + 1 : p;
+                *reinterpret_cast<u32x4*>(img + bb * board_bytes + pix * stride + c * 16) = v[u];
+            }
         }
     }
-    __syncthreads();
 
     // ---- this wave: board wave>>1, rows 4*(wave&1)..+3, all 64 channels of block cb
     const int wb = wave >> 1;
     const int lp = PIXMAP[lane & 31];
     const int py = 4 * (wave & 1) + (lp >> 3), px = lp & 7;
-    const unsigned b_base = wb * board_bytes + ((TAPS == 9) ? (py * PITCH + px) : (py * 8 + px)) * stride + h * 16;
+    const unsigned b_base = LDS_IMG + wb * board_bytes + ((TAPS == 9) ? (py * PITCH + px) : (py * 8 + px)) * stride + h * 16;
     f32x16 acc[2];
 #pragma unroll
     for (int ms = 0; ms < 2; ++ms)
@@ -129,19 +170,48 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs a)
             const float4 s = *reinterpret_cast<const float4*>(a.shift + cb * 64 + ms * 32 + 8 * g + 4 * h);
             acc[ms][4 * g + 0] = s.x; acc[ms][4 * g + 1] = s.y; acc[ms][4 * g + 2] = s.z; acc[ms][4 * g + 3] = s.w;
         }
-    const unsigned short* wp = a.w + ((size_t)cb * TAPS * KS * 2) * 512 + lane * 8;     // 512 elements per fragment
-    for (int tap = 0; tap < TAPS; ++tap) {
-        const unsigned toff = (TAPS == 9) ? (unsigned)(((tap / 3) * PITCH + (tap % 3)) * stride) : 0u;
-#pragma unroll 4
-        for (int ks = 0; ks < KS; ++ks) {
-            const V b = *reinterpret_cast<const V*>(smem + b_base + toff + ks * 32);
-            const unsigned short* f = wp + ((size_t)(tap * KS + ks) * 2) * 512;
-            const V a0 = *reinterpret_cast<const V*>(f);
-            const V a1 = *reinterpret_cast<const V*>(f + 512);
-            acc[0] = Elem<T>::mfma(a0, b, acc[0]);
-            acc[1] = Elem<T>::mfma(a1, b, acc[1]);
-        }
+    // byte offset of the first k-step of chunk n in the image, relative to b_base
+    auto chunk_off = [&](int n) -> unsigned {
+        const int tap = n / CPT, q = n - tap * CPT;
+        return ((TAPS == 9) ? (unsigned)(((tap / 3) * PITCH + (tap % 3)) * stride) : 0u) + q * 128;
+    };
+    // image staged + chunk 0 landed, for everybody
+    asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(2 * (RD - 2)) : "memory");
+    V A[2][8], Bq[2][4];
+#pragma unroll
+    for (int f = 0; f < 8; ++f) A[0][f] = *reinterpret_cast<const V*>(smem + lane * 16 + f * 1024);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) Bq[0][k] = *reinterpret_cast<const V*>(smem + b_base + chunk_off(0) + k * 32);
+
+    // one chunk step with register set CUR holding chunk n (see tower_mfma.hip for the protocol)
+#define KH_LAYER_STEP(CUR, n)                                                                          \
+    {                                                                                                  \
+        asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(2 * (RD - 3)) : "memory");               \
+        __builtin_amdgcn_sched_barrier(0);                                                             \
+        ring_issue(stream, NCH, (n) + RD - 1, wave, lane);                                             \
+        const unsigned a_off = (unsigned)((((n) + 1) % RD) * CHUNKB) + lane * 16;                      \
+        _Pragma("unroll") for (int f = 0; f < 8; ++f)                                                  \
+            A[(CUR) ^ 1][f] = *reinterpret_cast<const V*>(smem + a_off + f * 1024);                    \
+        const unsigned bo = chunk_off(((n) + 1 < NCH) ? (n) + 1 : (n));                                \
+        _Pragma("unroll") for (int k = 0; k < 4; ++k)                                                  \
+            Bq[(CUR) ^ 1][k] = *reinterpret_cast<const V*>(smem + b_base + bo + k * 32);                \
+        _Pragma("unroll") for (int k = 0; k < 4; ++k) {                                                \
+            acc[0] = Elem<T>::mfma(A[CUR][2 * k], Bq[CUR][k], acc[0]);                                 \
+            acc[1] = Elem<T>::mfma(A[CUR][2 * k + 1], Bq[CUR][k], acc[1]);                             \
+        }                                                                                              \
+        _Pragma("unroll") for (int i = 0; i < 8; ++i) {                                                \
+            __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);                                         \
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                         \
+        }                                                                                              \
     }
+    int n = 0;
+    for (; n + 1 < NCH; n += 2) {
+        KH_LAYER_STEP(0, n)
+        KH_LAYER_STEP(1, n + 1)
+    }
+    if (n < NCH) KH_LAYER_STEP(0, n)
+#undef KH_LAYER_STEP
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // drain the ring (tail re-fetches) before exit
 
     // ---- epilogue
     const int b = b0 + wb;
@@ -257,20 +327,24 @@ __global__ __launch_bounds__(256) void conv_f32_kernel(ConvArgsF32 a)
             acc[ms][4 * g + 0] = s.x; acc[ms][4 * g + 1] = s.y; acc[ms][4 * g + 2] = s.z; acc[ms][4 * g + 3] = s.w;
         }
     const float* wp = a.w + ((size_t)cb * TAPS * KJ * 2) * 256 + lane * 4;     // 256 floats per fragment
-    for (int tap = 0; tap < TAPS; ++tap) {
-        const unsigned toff = (TAPS == 9) ? (unsigned)(((tap / 3) * PITCH + (tap % 3)) * stride) : 0u;
-#pragma unroll 2
-        for (int j = 0; j < KJ; ++j) {
-            const f32x4v b = *reinterpret_cast<const f32x4v*>(smem + b_base + toff + j * 32);
-            const float* f = wp + ((size_t)(tap * KJ + j) * 2) * 256;
-            const f32x4v a0 = *reinterpret_cast<const f32x4v*>(f);
-            const f32x4v a1 = *reinterpret_cast<const f32x4v*>(f + 256);
+    const int TK = TAPS * KJ;
+    auto boff = [&](int kk) -> unsigned {
+        const int tap = kk / KJ, j = kk - tap * KJ;
+        return ((TAPS == 9) ? (unsigned)(((tap / 3) * PITCH + (tap % 3)) * stride) : 0u) + j * 32;
+    };
+    f32x4v bq = *reinterpret_cast<const f32x4v*>(smem + b_base + boff(0));
+    f32x4v a0 = *reinterpret_cast<const f32x4v*>(wp), a1 = *reinterpret_cast<const f32x4v*>(wp + 256);
+    for (int kk = 0; kk < TK; ++kk) {
+        const int kn = (kk + 1 < TK) ? kk + 1 : kk;
+        const f32x4v bn = *reinterpret_cast<const f32x4v*>(smem + b_base + boff(kn));
+        const f32x4v a0n = *reinterpret_cast<const f32x4v*>(wp + (size_t)kn * 512);
+        const f32x4v a1n = *reinterpret_cast<const f32x4v*>(wp + (size_t)kn * 512 + 256);
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[i], b[i], acc[0], 0, 0, 0);
-                acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[i], b[i], acc[1], 0, 0, 0);
-            }
+        for (int i = 0; i < 4; ++i) {
+            acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[i], bq[i], acc[0], 0, 0, 0);
+            acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[i], bq[i], acc[1], 0, 0, 0);
         }
+        a0 = a0n; a1 = a1n; bq = bn;
     }
     const int b = b0 + wb;
     if (b >= a.B) return;
@@ -373,7 +447,7 @@ static hipError_t run_f32(const LayersArgs& L, hipStream_t s)
 template <typename T, int TAPS, int EPI> static hipError_t launch_conv(const ConvArgs& a, hipStream_t s)
 {
     const int stride = a.Ci * 2 + 16;
-    const int lds = 2 * ((TAPS == 9) ? NPIX : 64) * stride;
+    const int lds = LDS_IMG + 2 * ((TAPS == 9) ? NPIX : 64) * stride;
     static bool attr_done = false;
     if (!attr_done) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_mfma_kernel<T, TAPS, EPI>),
@@ -422,7 +496,7 @@ template <typename T> static hipError_t run(const LayersArgs& L, hipStream_t s)
 
 }  // namespace lay
 
-size_t layers_lds_bytes(int Ci) { return (size_t)2 * lay::NPIX * (Ci * 2 + 16); }
+size_t layers_lds_bytes(int Ci) { return (size_t)lay::LDS_IMG + (size_t)2 * lay::NPIX * (Ci * 2 + 16); }
 
 hipError_t launch_layers(int dtype, const LayersArgs& L, hipStream_t s)
 {
