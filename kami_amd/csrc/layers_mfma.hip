@@ -332,19 +332,26 @@ __global__ __launch_bounds__(256) void conv_f32_kernel(ConvArgsF32 a)
         const int tap = kk / KJ, j = kk - tap * KJ;
         return ((TAPS == 9) ? (unsigned)(((tap / 3) * PITCH + (tap % 3)) * stride) : 0u) + j * 32;
     };
-    f32x4v bq = *reinterpret_cast<const f32x4v*>(smem + b_base + boff(0));
-    f32x4v a0 = *reinterpret_cast<const f32x4v*>(wp), a1 = *reinterpret_cast<const f32x4v*>(wp + 256);
+    // operands two k-groups ahead in flight: one group is 8 MFMAs x 64 cycles, about one L2 round trip
+    auto ld = [&](int kk, f32x4v& x0, f32x4v& x1, f32x4v& xb) {
+        const int k = kk < TK ? kk : TK - 1;                       // past the end: harmless re-read
+        xb = *reinterpret_cast<const f32x4v*>(smem + b_base + boff(k));
+        x0 = *reinterpret_cast<const f32x4v*>(wp + (size_t)k * 512);
+        x1 = *reinterpret_cast<const f32x4v*>(wp + (size_t)k * 512 + 256);
+    };
+    f32x4v a0, a1, bq, a0n, a1n, bn;
+    ld(0, a0, a1, bq);
+    ld(1, a0n, a1n, bn);
     for (int kk = 0; kk < TK; ++kk) {
-        const int kn = (kk + 1 < TK) ? kk + 1 : kk;
-        const f32x4v bn = *reinterpret_cast<const f32x4v*>(smem + b_base + boff(kn));
-        const f32x4v a0n = *reinterpret_cast<const f32x4v*>(wp + (size_t)kn * 512);
-        const f32x4v a1n = *reinterpret_cast<const f32x4v*>(wp + (size_t)kn * 512 + 256);
+        f32x4v a0f, a1f, bf;
+        ld(kk + 2, a0f, a1f, bf);
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[i], bq[i], acc[0], 0, 0, 0);
             acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[i], bq[i], acc[1], 0, 0, 0);
         }
         a0 = a0n; a1 = a1n; bq = bn;
+        a0n = a0f; a1n = a1f; bn = bf;
     }
     const int b = b0 + wb;
     if (b >= a.B) return;
