@@ -153,6 +153,11 @@ int  kh_infer_device(kh_engine* e, const void* d_input, int batch,
                      float* d_policy, float* d_value_full, void* stream);
 int  kh_encode_device(kh_engine* e, const kh_board* d_boards, int batch,
                       float* d_planes, void* stream);
+/* Compact ingest, device-resident: records in, policy / value tensor out.  With a bf16 / f16 engine
+ * of <= 64 filters the encoder runs INSIDE the forward kernel (no planes in HBM); otherwise the
+ * encode kernel writes planes to engine scratch first.  Requires cfg.features == 30. */
+int  kh_encode_infer_device(kh_engine* e, const kh_board* d_boards, int batch,
+                            float* d_policy, float* d_value_full, void* stream);
 
 /* Timing helper for bench/roofline: runs `iters` back-to-back kh_infer_device
  * launches on the engine stream bracketed by HIP events recorded on THAT stream

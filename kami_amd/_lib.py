@@ -46,6 +46,7 @@ SYMBOLS = {
     "kh_encode_infer_legal": (C.c_int, [_P, _P, C.c_int, _P, _P, _P, _P]),
     "kh_infer_device": (C.c_int, [_P, _P, C.c_int, _P, _P, _P]),
     "kh_encode_device": (C.c_int, [_P, _P, C.c_int, _P, _P]),
+    "kh_encode_infer_device": (C.c_int, [_P, _P, C.c_int, _P, _P, _P]),
     "kh_time_infer_device": (C.c_int, [_P, _P, C.c_int, _P, _P, C.c_int, C.POINTER(C.c_float)]),
     "kh_time_encode_device": (C.c_int, [_P, _P, C.c_int, _P, C.c_int, C.POINTER(C.c_float)]),
     "kh_dev_alloc": (C.c_int, [_P, C.c_size_t, C.POINTER(_P)]),

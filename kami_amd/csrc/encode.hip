@@ -9,6 +9,7 @@
 //   phase 2  the tile is streamed to HBM as 480 fully coalesced 16-byte stores.
 // The record itself is wave-uniform and is fetched with scalar loads.
 #include "kh_internal.h"
+#include "encode_square.h"
 
 namespace kh {
 
@@ -27,32 +28,8 @@ __global__ __launch_bounds__(64 * ENC_WAVES) void encode_f32_kernel(const kh_boa
     for (int base = blockIdx.x * ENC_WAVES; base < n; base += stride) {
         const int b = base + wave;            // wave-uniform
         if (b < n) {
-            const kh_board* r = boards + b;
-            const int ply = r->ply, hmc = r->halfmove_clock;
-            const int ctm = r->ctm & 1, castle = r->castle_rights;
-            // real square seen at POV square `lane` (env.h:246: povsq = 63 - sq for black)
-            const int sq = ctm ? 63 - lane : lane;
-            // piece plane index 0..11 relative to channel 18, or -1 for an empty square
-            int idx = -1;
-#pragma unroll
-            for (int t = 0; t < 6; ++t)
-                if ((r->piece_occ[t] >> sq) & 1) idx = t;
-            const int is_w = (int)((r->color_occ[0] >> sq) & 1);
-            const int is_b = (int)((r->color_occ[1] >> sq) & 1);
-            if (!(is_w | is_b)) idx = -1;
-            // ncPieceColor(pc) != our_col -> +6 (env.h:255-256)
-            if (idx >= 0 && (is_b != ctm)) idx += 6;
-
             float v[KH_NFEATURES];
-#pragma unroll
-            for (int i = 0; i < 8; ++i) v[i] = (float)((ply >> i) & 1);                 // env.h:213-214
-#pragma unroll
-            for (int i = 0; i < 6; ++i) v[8 + i] = (float)((hmc >> i) & 1);             // env.h:216-218
-            // raw masked castle bits; black swaps the white/black pairs (env.h:220-236)
-#pragma unroll
-            for (int i = 0; i < 4; ++i) v[14 + i] = (float)(castle & (1 << (i ^ (ctm << 1))));
-#pragma unroll
-            for (int i = 0; i < 12; ++i) v[18 + i] = (idx == i) ? 1.0f : 0.0f;         // env.h:258
+            encode_square(boards + b, lane, v);
 
             float2* dst = reinterpret_cast<float2*>(tile + lane * KH_NFEATURES);         // 120 B rows: 8-B aligned
 #pragma unroll

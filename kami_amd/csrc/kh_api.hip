@@ -448,10 +448,10 @@ int forward_simple(kh_engine* e, const Weights& W, Slot& s, const float* d_in, i
 
 // The throughput path: one persistent kernel for the whole forward pass (tower_mfma.hip).
 int forward_tower(kh_engine* e, const Weights& W, Slot& s, const float* d_in, int B,
-                  float* d_policy, float* d_vfull, float* d_logits_out)
+                  float* d_policy, float* d_vfull, float* d_logits_out, const kh_board* d_boards = nullptr)
 {
     if (!W.tw_ok) return fail(KH_ERR_INVALID, "bf16/f16 path unavailable for this configuration: %s", W.tw_why.c_str());
-    if (reinterpret_cast<uintptr_t>(d_in) & 15) return fail(KH_ERR_INVALID, "input planes must be 16-byte aligned");
+    if (!d_boards && (reinterpret_cast<uintptr_t>(d_in) & 15)) return fail(KH_ERR_INVALID, "input planes must be 16-byte aligned");
     hipStream_t st = s.stream;
     int* flags = s.flags.as<int>();
     if (!s.flags_clean) {               // NaN flags are only ever OR-ed by the kernel: clear on demand,
@@ -459,7 +459,7 @@ int forward_tower(kh_engine* e, const Weights& W, Slot& s, const float* d_in, in
         s.flags_clean = true;
     }
     kh::TowerArgs a;
-    a.in = d_in; a.B = B; a.F = e->cfg.features; a.R = e->cfg.residuals;
+    a.in = d_in; a.boards = d_boards; a.B = B; a.F = e->cfg.features; a.R = e->cfg.residuals;
     a.wstream = W.tw_stream.as<char>(); a.nchunks = W.tw_nchunks;
     a.params = W.tw_par.as<float>(); a.npar = W.tw_npar;
     a.fcw4 = W.tw_fc4.as<float>(); a.fcb = W.tw_fc4.as<float>() + (size_t)KH_VALUE_WIDTH * 64;
@@ -538,6 +538,12 @@ int check_cfg(const kh_config* c)
     return KH_OK;
 }
 
+// Env::observe can run inside the forward kernel: bf16 / f16 tower kernel with the encoder's 30 planes
+bool fused_ingest(const kh_engine* e, const Weights& W)
+{
+    return e->cfg.dtype != KH_F32 && W.tw_ok && W.tw_FP == 32 && e->cfg.features == KH_NFEATURES;
+}
+
 struct LegalIO { const int32_t* offsets; const int32_t* actions; float* priors; };
 
 int infer_host(kh_engine* e, const float* input, const kh_board* boards, int batch,
@@ -564,17 +570,19 @@ int infer_host(kh_engine* e, const float* input, const kh_board* boards, int bat
     const size_t B = batch, F = e->cfg.features;
     hipStream_t st = s.stream;
     const float* d_in;
+    const bool fused = boards && fused_ingest(e, *W) && !logits;
     if (boards) {
         HIPCHK(hipMemcpyAsync(s.boards.p, boards, B * sizeof(kh_board), hipMemcpyHostToDevice, st));
-        kh::launch_encode_f32(s.boards.as<kh_board>(), batch, s.planes.as<float>(), st);
+        if (!fused) kh::launch_encode_f32(s.boards.as<kh_board>(), batch, s.planes.as<float>(), st);
         d_in = s.planes.as<float>();
     } else {
         HIPCHK(hipMemcpyAsync(s.in.p, input, B * 64 * F * 4, hipMemcpyHostToDevice, st));   // nn.cpp:160
         d_in = s.in.as<float>();
     }
     float* d_logits = logits ? s.logits.as<float>() : nullptr;
-    if ((rc = forward_dispatch(e, *W, s, d_in, batch, s.policy.as<float>(), s.vfull.as<float>(), d_logits)))
-        return rc;
+    if (fused) rc = forward_tower(e, *W, s, nullptr, batch, s.policy.as<float>(), s.vfull.as<float>(), nullptr, s.boards.as<kh_board>());
+    else rc = forward_dispatch(e, *W, s, d_in, batch, s.policy.as<float>(), s.vfull.as<float>(), d_logits);
+    if (rc) return rc;
     int flags[4] = { 0, 0, 0, 0 };
     if (legal && nact > 0) {
         if (s.offs.ensure((B + 1) * 4) || s.acts.ensure((size_t)nact * 4) || s.priors.ensure((size_t)nact * 4)) return KH_ERR_HIP;
@@ -814,6 +822,33 @@ int kh_encode_device(kh_engine* e, const kh_board* d_boards, int batch, float* d
     kh::launch_encode_f32(d_boards, batch, d_planes, stream ? static_cast<hipStream_t>(stream) : s.stream);
     HIPCHK(hipGetLastError());
     return KH_OK;
+}
+
+int kh_encode_infer_device(kh_engine* e, const kh_board* d_boards, int batch, float* d_policy,
+                           float* d_value_full, void* stream)
+{
+    if (!e || !d_boards || !d_policy || !d_value_full) return fail(KH_ERR_INVALID, "null argument");
+    if (batch < 1) return fail(KH_ERR_INVALID, "batch must be >= 1");
+    if (e->cfg.features != KH_NFEATURES)
+        return fail(KH_ERR_INVALID, "kh_encode_infer_device needs features == %d (Env::observe planes)", KH_NFEATURES);
+    auto W = current_weights(e);
+    if (!W) return fail(KH_ERR_NO_WEIGHTS, "kh_encode_infer_device before kh_load_weights");
+    int rc = set_device(e);
+    if (rc) return rc;
+    std::lock_guard<std::mutex> lk(e->dmu);
+    Slot* s;
+    if ((rc = dev_slot(e, batch, stream, &s))) return rc;
+    hipStream_t own = s->stream;
+    if (stream) s->stream = static_cast<hipStream_t>(stream);
+    if (fused_ingest(e, *W)) {
+        rc = forward_tower(e, *W, *s, nullptr, batch, d_policy, d_value_full, nullptr, d_boards);
+    } else {
+        if (s->planes.ensure((size_t)batch * 64 * KH_NFEATURES * 4)) { s->stream = own; return KH_ERR_HIP; }
+        kh::launch_encode_f32(d_boards, batch, s->planes.as<float>(), s->stream);
+        rc = forward_dispatch(e, *W, *s, s->planes.as<float>(), batch, d_policy, d_value_full, nullptr);
+    }
+    s->stream = own;
+    return rc;
 }
 
 static int time_loop(kh_engine* e, int iters, float* ms, int (*body)(void*), void* ctx)

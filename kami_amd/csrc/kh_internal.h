@@ -42,7 +42,8 @@ constexpr int TW_NB = 2;     // boards per workgroup pass
 constexpr int TW_CP = 64;    // channel count the kernel is specialised for (smaller nets are zero-padded)
 
 struct TowerArgs {
-    const float* in;         // [B][8][8][F] fp32 planes
+    const float* in;         // [B][8][8][F] fp32 planes (ignored when boards != nullptr)
+    const kh_board* boards;  // nullable: compact ingest, Env::observe fused into the kernel (F must be 30)
     int B, F, R;
     const char* wstream;     // packed weight fragments, nchunks x 8 KB (see pack_tower in kh_api.hip)
     int nchunks;

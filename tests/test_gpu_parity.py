@@ -233,6 +233,23 @@ def test_encode_infer_equals_encode_then_infer(observe_fixture):
     assert np.array_equal(p1, p2) and np.array_equal(v1, v2)
 
 
+@pytest.mark.parametrize("dtype", ["bf16", "f16"])
+def test_fused_ingest_equals_encode_then_infer(observe_fixture, dtype):
+    """Compact ingest with the encoder INSIDE the forward kernel (bf16/f16, <= 64 filters) must equal
+    encode -> planes -> infer bit for bit: plane values 0/1/2/4/8 are exact in both formats."""
+    f = observe_fixture
+    sel = np.arange(0, len(f["fen"]), 5)[:201]                   # odd count: last group is half empty
+    boards = ko.boards_from_fens([f["fen"][i].decode() for i in sel], f["ply"][sel])
+    F, C, R = 30, 64, 2
+    nn = NN(8, 8, F, 4672, filters=C, residuals=R, dtype=dtype)
+    nn.load_weights(W.random_weights(F, C, R, seed=31, peaky=20.0), 3)
+    p1, v1 = nn.encode_infer(boards)                             # fused kernel
+    p2, v2 = nn.infer(nn.encode(boards))                         # encode kernel, planes through the host
+    assert np.array_equal(p1, p2) and np.array_equal(v1, v2)
+    op, ovf, _ = ko.forward(nn._blob, F, C, R, ko.observe(boards[:8]))
+    np.testing.assert_allclose(np.log(p1[:8]), np.log(op), atol=TOL[dtype]["logp"], rtol=0)
+
+
 def test_legal_move_gather_matches_expand_renormalisation(observe_fixture):
     """priors = policy[legal] / sum(policy[legal]) (MCTS::expand, mcts.h:273-276,296) with the
     reference's own legal-action lists (Env::actions) from the fixture."""
