@@ -680,6 +680,7 @@ hipError_t launch_tower(int dtype, int FP, const TowerArgs& a, int num_cus, hipS
 {
     const int ngroups = (a.B + TW_NB - 1) / TW_NB;
     const int grid = ngroups < num_cus ? ngroups : num_cus;      // one workgroup per CU (LDS-bound residency)
+#ifdef KAMI_TOWER_DIAG   // diagnostic variants (timing experiments, step stamps): KAMI_DIAG=1 python -m kami_amd.build
     const int dbg = getenv("KAMI_TOWER_DBG") ? atoi(getenv("KAMI_TOWER_DBG")) : 0;   // timing experiments (read per launch: in-process A/B, tools/ab_bench.py)
     static bool said = false;
     if (dbg && !said) { fprintf(stderr, "[kamihip] KAMI_TOWER_DBG=%d (timing experiment: results are WRONG) dtype=%d FP=%d\n", dbg, dtype, FP); said = true; }
@@ -708,6 +709,7 @@ hipError_t launch_tower(int dtype, int FP, const TowerArgs& a, int num_cus, hipS
         default: break;
         }
     }
+#endif
     if (dtype == KH_BF16) return FP == 32 ? launch<__bf16, 2>(a, grid, s) : launch<__bf16, 8>(a, grid, s);
     return FP == 32 ? launch<_Float16, 2>(a, grid, s) : launch<_Float16, 8>(a, grid, s);
 }
