@@ -142,8 +142,9 @@ uint16_t f2f16(float f)
 // Append one layer's MFMA A-operand fragments (v_mfma_f32_32x32x16: lane l = (r = l & 31, h = l >> 5)
 // holds W[co = ms*32 + r][k = 8h + j], j = 0..7) in consumption order tap -> k-step -> ms, BN scale
 // folded in before rounding, zero-padded to (MS*32, KS*16) and to a whole number of 8-fragment chunks.
+// ci0: first input channel of this pass (the 128-plane stem runs as two 64-channel passes).
 void pack_layer(std::vector<uint16_t>& out, int dtype, const float* w, const float* scale, int Co, int Ci,
-                int taps, int KS, int MS)
+                int taps, int KS, int MS, int ci0 = 0)
 {
     for (int tap = 0; tap < taps; ++tap)
         for (int ks = 0; ks < KS; ++ks)
@@ -151,7 +152,7 @@ void pack_layer(std::vector<uint16_t>& out, int dtype, const float* w, const flo
                 for (int l = 0; l < 64; ++l) {
                     const int r = l & 31, h = l >> 5;
                     for (int j = 0; j < 8; ++j) {
-                        const int co = ms * 32 + r, ci = ks * 16 + 8 * h + j;
+                        const int co = ms * 32 + r, ci = ci0 + ks * 16 + 8 * h + j;
                         float v = 0.0f;
                         if (co < Co && ci < Ci) v = w[((size_t)co * Ci + ci) * taps + tap] * (scale ? scale[co] : 1.0f);
                         out.push_back(dtype == KH_BF16 ? f2bf16(v) : f2f16(v));
@@ -248,7 +249,12 @@ int build_tower(Weights& W, const HostNet& n, int dtype, int F, int C, int R)
     std::vector<uint16_t> stream;
     std::vector<float> par((size_t)tower_par_copy_floats(R), 0.0f);
     fold_bn(n.stem, C, sc.data(), sh.data());
-    pack_layer(stream, dtype, n.stem.w, sc.data(), C, F, 9, FP / 16, 2);
+    if (FP == 128) {        // two 64-plane passes: the second half of the planes is still arriving during the first
+        pack_layer(stream, dtype, n.stem.w, sc.data(), C, F, 9, 4, 2, 0);
+        pack_layer(stream, dtype, n.stem.w, sc.data(), C, F, 9, 4, 2, 64);
+    } else {
+        pack_layer(stream, dtype, n.stem.w, sc.data(), C, F, 9, FP / 16, 2);
+    }
     memcpy(par.data(), sh.data(), sizeof(float) * C);
     for (int i = 0; i < 2 * R; ++i) {
         fold_bn(n.res[i], C, sc.data(), sh.data());

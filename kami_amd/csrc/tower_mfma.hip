@@ -157,12 +157,14 @@ __device__ __forceinline__ void pipe_issue(Pipe& p, int wave, int lane)
 // while the MFMAs of chunk c run.  A chunk is therefore requested D-2 steps before it is needed.
 // DBG (timing experiments only, results are wrong when non-zero): 1 = no s_barrier, 2 = no DMA
 // issue, 4 = no vmcnt wait.
-template <int DBG = 0>
+// VMX: vector-memory operations younger than the ring's that the wait must leave in flight (the
+// stem's first steps run under the tail of the prologue's loads, see the kernel).
+template <int DBG = 0, int VMX = 0>
 __device__ __forceinline__ unsigned pipe_step(Pipe& p, int wave, int lane)
 {
     unsigned long long t0 = 0, t1 = 0;
     if (DBG & 1024) t0 = __builtin_amdgcn_s_memtime();
-    if (!(DBG & 4)) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * (RING_D - 3)) : "memory");
+    if (!(DBG & 4)) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * (RING_D - 3) + VMX) : "memory");
     if (DBG & 1024) t1 = __builtin_amdgcn_s_memtime();
     if (!(DBG & 1)) asm volatile("s_barrier" ::: "memory");
     if (DBG & 1024) {
@@ -208,10 +210,14 @@ __device__ __forceinline__ constexpr unsigned b_offset(int kk, int stride)
     return (unsigned)((TAPS == 9 ? ((tap / 3) * PITCH + (tap % 3)) * stride : 0) + ks * 32);
 }
 
-template <typename T, int TAPS, int KS, int MS, int PAR, int DBG = 0>
+struct NoHook { __device__ __forceinline__ void operator()() const {} };
+
+// RELAX / VMX: the first RELAX steps wait with VMX extra operations allowed in flight; hook() runs
+// between step HOOK_AT - 1 and step HOOK_AT.
+template <typename T, int TAPS, int KS, int MS, int PAR, int DBG = 0, int RELAX = 0, int VMX = 0, int HOOK_AT = -1, class Hook = NoHook>
 __device__ __forceinline__ void gemm_layer(Pipe& p, const char* smem, int wave, int lane,
                                            unsigned b_base, int stride, f32x16 (&acc)[MS],
-                                           typename Elem<T>::vec8 (&A)[2][8])
+                                           typename Elem<T>::vec8 (&A)[2][8], const Hook& hook = Hook())
 {
     using V = typename Elem<T>::vec8;
     using S = LayerShape<TAPS, KS, MS>;
@@ -223,7 +229,8 @@ __device__ __forceinline__ void gemm_layer(Pipe& p, const char* smem, int wave, 
 #pragma unroll
     for (int n = 0; n < S::NCH; ++n) {
         const int cur = (PAR + n) & 1, nxt = cur ^ 1;
-        const unsigned a_off = pipe_step<DBG>(p, wave, lane) + lane * 16;
+        if (n == HOOK_AT) hook();
+        const unsigned a_off = (n < RELAX ? pipe_step<DBG, VMX>(p, wave, lane) : pipe_step<DBG>(p, wave, lane)) + lane * 16;
 #pragma unroll
         for (int f = 0; f < 8; ++f) {
             if (DBG & 16) A[nxt][f] = A[cur][f];
@@ -322,6 +329,79 @@ __device__ __forceinline__ float wave_sum_f(float v)
     return v;
 }
 
+
+// valuefc + tanh -> [B][256] (nn.cpp:86-88): thread j owns output j, its weight row sits in registers
+__device__ __forceinline__ void value_fc(const TowerArgs& a, const float4 (&fcw)[16], float fcbias, const float* v64,
+                                         int b0, int tid, int lane)
+{
+    float s[TW_NB];
+#pragma unroll
+    for (int bb = 0; bb < TW_NB; ++bb) s[bb] = 0.0f;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+        const float4 w = fcw[k];
+#pragma unroll
+        for (int bb = 0; bb < TW_NB; ++bb) {
+            const float4 x = *reinterpret_cast<const float4*>(v64 + bb * 64 + k * 4);
+            s[bb] = fmaf(x.x, w.x, s[bb]); s[bb] = fmaf(x.y, w.y, s[bb]);
+            s[bb] = fmaf(x.z, w.z, s[bb]); s[bb] = fmaf(x.w, w.w, s[bb]);
+        }
+    }
+    bool nan = false;
+#pragma unroll
+    for (int bb = 0; bb < TW_NB; ++bb) {
+        if (b0 + bb < a.B) {
+            const float r = tanhf(s[bb] + fcbias);
+            nan |= (r != r);
+            a.vfull[(size_t)(b0 + bb) * KH_VALUE_WIDTH + tid] = r;
+        }
+    }
+    if (__any(nan) && lane == 0) atomicOr(&a.flags[1], 1);
+}
+
+
+// Second stage of the 128-plane ingest: one half (64 channels) of this thread's four (board, pixel)
+// items -> T in the S image; flags non-finite inputs like the reference's NaN check (nn.cpp:176).
+template <typename T>
+__device__ __forceinline__ void ingest_half(const float4_u (&v)[4][2], int hh, char* simg, int sstr, int sboard,
+                                            int b0, int tid, int lane, const TowerArgs& a)
+{
+    const int F = a.F;
+    bool bad = false;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int bp = (tid >> 3) + 32 * j, bb = bp >> 6, p = bp & 63;
+        const bool live = (b0 + bb) < a.B;
+        char* dst = simg + bb * sboard + (((p >> 3) + 1) * PITCH + (p & 7) + 1) * sstr + hh * 128 + 8 * (tid & 7);
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const int c = hh * 64 + 32 * q + 4 * (tid & 7);
+            const int sh = c - min(c, F - 4);         // the load was moved back by sh channels; channels >= F are zero
+            float x[4] = { v[j][q].x, v[j][q].y, v[j][q].z, v[j][q].w };
+            if (sh != 0) {
+                float y[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    y[k] = 0.0f;
+#pragma unroll
+                    for (int m = 1; m < 4; ++m)
+                        if (k + m < 4 && sh == m) y[k] = x[k + m];
+                }
+#pragma unroll
+                for (int k = 0; k < 4; ++k) x[k] = y[k];
+            }
+            u32x2 o = { 0u, 0u };
+            if (live) {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) bad = bad || ((__float_as_uint(x[k]) & 0x7f800000u) == 0x7f800000u);
+                o.x = pack2<T>(x[0], x[1]); o.y = pack2<T>(x[2], x[3]);
+            }
+            *reinterpret_cast<u32x2*>(dst + 64 * q) = o;
+        }
+    }
+    if (__any(bad) && lane == 0) atomicOr(&a.flags[0], 1);
+}
+
 // ---------------------------------------------------------------- the kernel
 // KS_STEM = padded input planes / 16 (2 for F <= 32, 8 for F <= 128).
 template <typename T, int KS_STEM, int DBG = 0>
@@ -372,11 +452,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 #pragma unroll
     for (int i = 0; i < RING_D - 1; ++i) pipe_issue(pipe, wave, lane);
 
-    // valuefc row of this thread (output j = tid), kept in registers for the whole kernel
-    float4 fcw[16];
-#pragma unroll
-    for (int k = 0; k < 16; ++k) fcw[k] = reinterpret_cast<const float4*>(a.fcw4)[k * KH_VALUE_WIDTH + tid];
-    const float fcbias = a.fcb[tid];
     // parameter block -> LDS
     for (int i = tid; i < a.npar; i += 256) par[i] = a.params[i];
 
@@ -386,6 +461,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     constexpr int CH = FP / 8;             // 8-channel (16-byte) chunks per pixel of S
     constexpr int NIT = TW_NB * 64 * CH / 256;              // (board, pixel, chunk) items per thread
     bool first = true;
+    float4_u pl[2][4][2];                  // KS_STEM == 8: plane loads in flight, [half][item][+0 / +32 channels]
 
     const int ngroups = (a.B + TW_NB - 1) / TW_NB;
     for (int grp = blockIdx.x; grp < ngroups; grp += gridDim.x) {
@@ -426,6 +502,42 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                     *reinterpret_cast<u32x4*>(dst + c * 16) = o;
                 }
             }
+        } else
+        // ---- 1''. 33..128 planes: the stem runs as two 64-channel passes (the packer splits its
+        //          weights the same way) and only the first half of the planes is waited for here; the
+        //          second half lands under the first pass's steps and is converted by `ingest_h1`
+        //          between two of them.  Item j of a thread = (board, pixel) tid/8 + 32 j, channels
+        //          64 hh + 4 (tid%8) .. +3 and +32: every wave load covers 8 pixels x 128 contiguous
+        //          bytes.  Loads are clamped into the row / batch and masked afterwards so that every
+        //          wave issues exactly 8 loads per half (the counted vmcnt waits depend on it).
+        if (KS_STEM == 8) {
+            if (!(DBG & 64)) {
+#pragma unroll
+                for (int hh = 0; hh < 2; ++hh)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const int bp = (tid >> 3) + 32 * j;
+                        const int brd = min(b0 + (bp >> 6), a.B - 1);
+                        const float* row = a.in + ((size_t)brd * 64 + (bp & 63)) * F;
+                        const int c = hh * 64 + 4 * (tid & 7);
+                        pl[hh][j][0] = *reinterpret_cast<const float4_u*>(row + min(c, F - 4));
+                        pl[hh][j][1] = *reinterpret_cast<const float4_u*>(row + min(c + 32, F - 4));
+                    }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            // zero the halo pixels of X and S (the previous group's logits / policy image lived there)
+            const u32x4 z = { 0, 0, 0, 0 };
+            for (int i = tid; i < TW_NB * NPIX; i += 256) {
+                const int pp = i % NPIX, yy = pp / PITCH, xx = pp % PITCH;
+                if (yy >= 1 && yy <= 8 && xx >= 1 && xx <= 8) continue;
+                char* dx = smem + LDS_X + (i / NPIX) * XBOARD + pp * XSTR;
+#pragma unroll
+                for (int k = 0; k < XSTR / 16; ++k) *reinterpret_cast<u32x4*>(dx + k * 16) = z;
+                char* ds = smem + LDS_ST + (i / NPIX) * SBOARD + pp * SSTR;
+#pragma unroll
+                for (int k = 0; k < SSTR / 16; ++k) *reinterpret_cast<u32x4*>(ds + k * 16) = z;
+            }
+            if (!(DBG & 64)) ingest_half<T>(pl[0], 0, smem + LDS_ST, SSTR, SBOARD, b0, tid, lane, a);
         } else
         // ---- 1. planes fp32 [b][64][F] -> T in S (interior pixels, all FP channels); halos zeroed
         if (!(DBG & 64)) {
@@ -479,9 +591,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             // a NaN/Inf plane value makes the reference's policy NaN (nn.cpp:176): same verdict here
             if (__any(bad) && lane == 0) atomicOr(&a.flags[0], 1);
         }
+        // vector-memory operations of this wave that are younger than the ring's and may still be in
+        // flight past this point: the 8 loads of the second plane half
+        constexpr int VMX = KS_STEM == 8 ? 8 : 0;
         if (first) {
             // first group only: chunk 0 of the stream has landed -> first register set
-            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * (RING_D - 2)) : "memory");
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * (RING_D - 2) + VMX) : "memory");
             first = false;
             lds_barrier();
 #pragma unroll
@@ -494,7 +609,17 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         {
             f32x16 acc[2];
             acc_init<2>(acc, shift3, h);
-            gemm_layer<T, 9, KS_STEM, 2, 0, DBG & 1024>(pipe, smem, wave, lane, sin, SSTR, acc, A);
+            if (KS_STEM == 8) {
+                // pass 1 (planes 0..63): its first RING_D - 2 steps only need chunks that were requested
+                // before the plane loads, so their waits leave the second half's loads in flight
+                auto ingest_h1 = [&]() {
+                    if (!(DBG & 64)) ingest_half<T>(pl[1], 1, smem + LDS_ST, SSTR, SBOARD, b0, tid, lane, a);
+                };
+                gemm_layer<T, 9, 4, 2, 0, DBG & 1024, RING_D - 2, VMX, RING_D - 2>(pipe, smem, wave, lane, sin, SSTR, acc, A, ingest_h1);
+                gemm_layer<T, 9, 4, 2, 1, DBG & 1024>(pipe, smem, wave, lane, sin + 128, SSTR, acc, A);   // pass 2: planes 64..127
+            } else {
+                gemm_layer<T, 9, KS_STEM, 2, 0, DBG & 1024>(pipe, smem, wave, lane, sin, SSTR, acc, A);
+            }
             conv_epilogue<T, 2, false>(acc, smem, xout, h);
             lds_barrier();
             // T shares LDS with S: clear T's halo before the tower reads through it
@@ -542,37 +667,117 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             if (chk != chk) atomicOr(&a.flags[0], 1);
         }
 
+        // valuefc row of this thread (output j = tid): requested here, used after the softmax.  17 loads
+        // younger than the ring's: the next RING_D - 2 steps (two of 4b, two of 4c) leave them in flight.
+        float4 fcw[16];
+#pragma unroll
+        for (int k = 0; k < 16; ++k) fcw[k] = reinterpret_cast<const float4*>(a.fcw4)[k * KH_VALUE_WIDTH + tid];
+        const float fcbias = a.fcb[tid];
+        __builtin_amdgcn_sched_barrier(0);
+
         // ---- 4b. policy head: policyconv + pbatchnorm + relu, X -> P (128 ch)   nn.cpp:72-74
         {
             f32x16 acc[4];
             acc_init<4>(acc, pshift1, h);
-            gemm_layer<T, 1, TW_CP / 16, 4, P1, DBG & 1024>(pipe, smem, wave, lane, xin + (PITCH + 1) * XSTR, XSTR, acc, A);
+            gemm_layer<T, 1, TW_CP / 16, 4, P1, DBG & 1024, 2, 17>(pipe, smem, wave, lane, xin + (PITCH + 1) * XSTR, XSTR, acc, A);
             conv_epilogue<T, 4, false>(acc, smem, pout, h);
             lds_barrier();
         }
+        // ---- 4e'. (timing variant) value FC before the policy steps: +0.13 us
+        if ((DBG & 2048) && !(DBG & 256)) value_fc(a, fcw, fcbias, v64, b0, tid, lane);
 
         // ---- 4c. policyconv2 (+bias): P -> logits L[board][pixel*73 + plane]    nn.cpp:75-79
         {
             f32x16 acc[4];                  // 73 planes padded to 128 rows: whole 2-k-step chunks
             acc_init<4>(acc, pbias2, h);
-            gemm_layer<T, 1, KH_POLICY_MID / 16, 4, P1, DBG & 1024>(pipe, smem, wave, lane, pin, PSTR, acc, A);
+            gemm_layer<T, 1, KH_POLICY_MID / 16, 4, P1, DBG & 1024, RING_D - 4, 17>(pipe, smem, wave, lane, pin, PSTR, acc, A);
             if (P1) gemm_dummy<T, 1>(pipe, smem, wave, lane, A);      // stream parity back to 0 for the next group
             float* lrow = reinterpret_cast<float*>(smem + LDS_L + wb * LBOARD) + (py * 8 + px) * KH_POLICY_PLANES;
+            if (!(DBG & 4096)) {    // raw logits to LDS, softmax below
 #pragma unroll
-            for (int ms = 0; ms < 3; ++ms)      // planes >= 96 are padding
+                for (int ms = 0; ms < 3; ++ms)      // planes >= 96 are padding
 #pragma unroll
-                for (int g = 0; g < 4; ++g)
+                    for (int g = 0; g < 4; ++g)
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) {
-                        const int plane = ms * 32 + 8 * g + 4 * h + i;
-                        if (plane < KH_POLICY_PLANES) lrow[plane] = acc[ms][4 * g + i];
+                        for (int i = 0; i < 4; ++i) {
+                            const int plane = ms * 32 + 8 * g + 4 * h + i;
+                            if (plane < KH_POLICY_PLANES) lrow[plane] = acc[ms][4 * g + i];
+                        }
+                lds_barrier();
+            } else if (!(DBG & 128)) {
+                // ---- 4d'. (timing variant, +-0) softmax straight from the accumulators: max -> exp / sum in
+                //           registers, one transposing pass through LDS
+                const bool live = (b0 + wb) < a.B;
+                if (a.logits && live && !(DBG & 1024)) {     // diagnostic output (kh_infer_full): uncoalesced, off the timed path
+                    float* lg = a.logits + (size_t)(b0 + wb) * KH_PSIZE + (py * 8 + px) * KH_POLICY_PLANES;
+#pragma unroll
+                    for (int ms = 0; ms < 3; ++ms)
+#pragma unroll
+                        for (int g = 0; g < 4; ++g)
+#pragma unroll
+                            for (int i = 0; i < 4; ++i) {
+                                const int plane = ms * 32 + 8 * g + 4 * h + i;
+                                if (plane < KH_POLICY_PLANES) lg[plane] = acc[ms][4 * g + i];
+                            }
+                }
+                float m = -INFINITY;
+#pragma unroll
+                for (int ms = 0; ms < 3; ++ms)
+#pragma unroll
+                    for (int g = 0; g < 4; ++g)
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) {
+                            const int plane = ms * 32 + 8 * g + 4 * h + i;
+                            if (ms * 32 + 8 * g + i < KH_POLICY_PLANES)      // (false for both h: no code)
+                                m = fmaxf(m, plane < KH_POLICY_PLANES ? acc[ms][4 * g + i] : -INFINITY);
+                        }
+                m = wave_max_f(m);
+                if (lane == 0) red[wave] = m;
+                lds_barrier();
+                m = fmaxf(red[wb * 2], red[wb * 2 + 1]);
+                float sum = 0.0f;
+#pragma unroll
+                for (int ms = 0; ms < 3; ++ms)
+#pragma unroll
+                    for (int g = 0; g < 4; ++g)
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) {
+                            const int plane = ms * 32 + 8 * g + 4 * h + i;
+                            if (ms * 32 + 8 * g + i < KH_POLICY_PLANES && plane < KH_POLICY_PLANES) {
+                                const float e = __expf(acc[ms][4 * g + i] - m);
+                                sum += e;
+                                lrow[plane] = e;
+                            }
+                        }
+                sum = wave_sum_f(sum);
+                if (lane == 0) red[4 + wave] = sum;
+                lds_barrier();
+                const float inv = 1.0f / (red[4 + wb * 2] + red[4 + wb * 2 + 1]);
+                const int tt = tid & 127;
+                const float4* L4 = reinterpret_cast<const float4*>(smem + LDS_L + wb * LBOARD);
+                constexpr int NQ = KH_PSIZE / 4;               // 1168 float4 = 9 * 128 + 16
+                bool nan = false;
+                if (live) {
+                    using f4 = float __attribute__((ext_vector_type(4)));
+                    f4* po = reinterpret_cast<f4*>(a.policy + (size_t)(b0 + wb) * KH_PSIZE);
+#pragma unroll
+                    for (int k = 0; k < 10; ++k) {
+                        const int q = tt + 128 * k;
+                        if (q < NQ) {
+                            const float4 v = L4[q];
+                            const f4 o = { v.x * inv, v.y * inv, v.z * inv, v.w * inv };
+                            nan |= (o.x != o.x) | (o.y != o.y) | (o.z != o.z) | (o.w != o.w);
+                            __builtin_nontemporal_store(o, po + q);        // write-once stream
+                        }
                     }
-            lds_barrier();
+                }
+                if (__any(nan) && lane == 0) atomicOr(&a.flags[0], 1);
+            }
         }
 
-        // ---- 4d. softmax over all 4672 logits of a board (nn.cpp:80); 128 threads per board,
-        //          one LDS pass: each thread keeps its <= 10 float4 in registers
-        if (!(DBG & 128)) {
+        // ---- 4d. softmax over all 4672 logits of a board (nn.cpp:80): 128 threads per board, one LDS
+        //          pass, each thread keeps its <= 10 float4 in registers
+        if (!(DBG & 4096) && !(DBG & 128)) {
             const int bb = tid >> 7, tt = tid & 127;
             const bool live = (b0 + bb) < a.B;
             const float4* L4 = reinterpret_cast<const float4*>(smem + LDS_L + bb * LBOARD);
@@ -615,7 +820,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                     float4 o;
                     o.x = v[k].x * inv; o.y = v[k].y * inv; o.z = v[k].z * inv; o.w = v[k].w * inv;
                     nan |= (o.x != o.x) | (o.y != o.y) | (o.z != o.z) | (o.w != o.w);
-                    if (tt + 128 * k < NQ) {        // write-once stream: non-temporal
+                    if (tt + 128 * k < NQ) {
                         using f4 = float __attribute__((ext_vector_type(4)));
                         const f4 ov = { o.x, o.y, o.z, o.w };
                         __builtin_nontemporal_store(ov, reinterpret_cast<f4*>(po) + tt + 128 * k);
@@ -626,31 +831,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         }
 
         // ---- 4e. value head, second half: valuefc + tanh -> [B][256]            nn.cpp:86-88
-        if (!(DBG & 256)) {
-            float s[TW_NB];
-#pragma unroll
-            for (int bb = 0; bb < TW_NB; ++bb) s[bb] = 0.0f;
-#pragma unroll
-            for (int k = 0; k < 16; ++k) {
-                const float4 w = fcw[k];
-#pragma unroll
-                for (int bb = 0; bb < TW_NB; ++bb) {
-                    const float4 x = *reinterpret_cast<const float4*>(v64 + bb * 64 + k * 4);
-                    s[bb] = fmaf(x.x, w.x, s[bb]); s[bb] = fmaf(x.y, w.y, s[bb]);
-                    s[bb] = fmaf(x.z, w.z, s[bb]); s[bb] = fmaf(x.w, w.w, s[bb]);
-                }
-            }
-            bool nan = false;
-#pragma unroll
-            for (int bb = 0; bb < TW_NB; ++bb) {
-                if (b0 + bb < a.B) {
-                    const float r = tanhf(s[bb] + fcbias);
-                    nan |= (r != r);
-                    a.vfull[(size_t)(b0 + bb) * KH_VALUE_WIDTH + tid] = r;
-                }
-            }
-            if (__any(nan) && lane == 0) atomicOr(&a.flags[1], 1);
-        }
+        if (!(DBG & 2048) && !(DBG & 256)) value_fc(a, fcw, fcbias, v64, b0, tid, lane);
         lds_barrier();      // L / v64 are dead; the next group may overwrite them
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // drain the prefetch ring before exit
@@ -706,6 +887,9 @@ hipError_t launch_tower(int dtype, int FP, const TowerArgs& a, int num_cus, hipS
         case 34: return launch<__bf16, 8, 34>(a, grid, s);
         case 56: return launch<__bf16, 8, 56>(a, grid, s);
         case 27: return launch<__bf16, 8, 27>(a, grid, s);
+        case 2048: return launch<__bf16, 8, 2048>(a, grid, s);
+        case 4096: return launch<__bf16, 8, 4096>(a, grid, s);
+        case 6144: return launch<__bf16, 8, 6144>(a, grid, s);
         default: break;
         }
     }

@@ -96,7 +96,9 @@ def test_forward_mfma_vs_reference_fixtures(net_fixture, dtype):
 
 
 @pytest.mark.parametrize("dtype", ["f16", "bf16"])
-@pytest.mark.parametrize("F,C,R,B", [(119, 64, 6, 64), (30, 64, 6, 33), (30, 24, 1, 7), (119, 64, 0, 3)])
+@pytest.mark.parametrize("F,C,R,B", [(119, 64, 6, 64), (30, 64, 6, 33), (30, 24, 1, 7), (119, 64, 0, 3),
+                                     # 33..128 planes take the two-pass stem: ragged rows on both sides of the split
+                                     (33, 64, 1, 5), (61, 48, 1, 3), (64, 64, 1, 4), (67, 64, 1, 3), (100, 64, 2, 7), (128, 64, 1, 2)])
 def test_forward_mfma_vs_oracle(dtype, F, C, R, B):
     blob = W.random_weights(F, C, R, seed=F + C + R, peaky=20.0)
     x = np.random.default_rng(B).random((B, 8, 8, F), dtype=np.float32)
@@ -138,6 +140,21 @@ def test_mfma_nan_guard():
     xb[2, 3, 3, 1] = np.nan
     with pytest.raises(KamiError) as ei:
         nn.infer(xb)
+    assert ei.value.status == L.KH_ERR_NAN_POLICY
+
+
+@pytest.mark.parametrize("ch", [0, 63, 64, 118])
+def test_mfma_nan_guard_two_pass_stem(ch):
+    """F = 119 ingests the planes in two halves (channels < 64 before the stem, the rest under it):
+    a non-finite plane in either half, in the last board of an odd batch, is still flagged."""
+    F, C, R = 119, 64, 1
+    nn = NN(8, 8, F, 4672, filters=C, residuals=R, dtype="bf16")
+    nn.load_weights(W.random_weights(F, C, R, seed=3), 1)
+    x = np.random.default_rng(0).random((3, 8, 8, F), dtype=np.float32)
+    nn.infer(x)
+    x[2, 7, 7, ch] = np.inf
+    with pytest.raises(KamiError) as ei:
+        nn.infer(x)
     assert ei.value.status == L.KH_ERR_NAN_POLICY
 
 

@@ -2,7 +2,15 @@
 import sys, os, ctypes as C, numpy as np
 sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
 from kami_amd import NN, weights as W, _lib as L
-variants = [int(v) for v in sys.argv[1].split(",")] if len(sys.argv) > 1 else [0]
+if os.environ.get("KAMI_AB_LIB"):      # time another build of the library on the same box (tools only)
+    L.LIB_PATH = os.path.abspath(os.environ["KAMI_AB_LIB"])
+# a variant is "DBG" or "DBGsSTAGGER" (KAMI_TOWER_DBG bits, KAMI_TOWER_STAGGER value)
+variants = sys.argv[1].split(",") if len(sys.argv) > 1 else ["0"]
+def select(v):
+    d, _, st = v.partition("s")
+    os.environ["KAMI_TOWER_DBG"] = d
+    if st: os.environ["KAMI_TOWER_STAGGER"] = st
+    else: os.environ.pop("KAMI_TOWER_STAGGER", None)
 rounds = int(sys.argv[2]) if len(sys.argv) > 2 else 7
 F, Cc, R, B = 119, 64, 6, 512
 nn = NN(8, 8, F, 4672, filters=Cc, residuals=R, dtype="bf16")
@@ -15,18 +23,18 @@ lib.kh_memcpy_h2d(nn.handle, d_in, x.ctypes.data_as(C.c_void_p), x.nbytes)
 res = {v: [] for v in variants}
 for r in range(rounds):
     for v in variants:
-        os.environ["KAMI_TOWER_DBG"] = str(v)
+        select(v)
         ms = C.c_float()
         assert lib.kh_time_infer_device(nn.handle, d_in, B, d_p, d_v, 300, C.byref(ms)) == 0
         res[v].append(ms.value * 1e3)
 for v in variants:
     a = np.array(res[v][1:])
-    print(f"DBG {v:5d}: median {np.median(a):.2f} us  min {a.min():.2f}  max {a.max():.2f}")
+    print(f"DBG {v:>9s}: median {np.median(a):.2f} us  min {a.min():.2f}  max {a.max():.2f}")
 # correctness of the variants that claim to be result-preserving (pass e.g. "check" as 3rd arg)
 if len(sys.argv) > 3:
     outs = {}
     for v in variants:
-        os.environ["KAMI_TOWER_DBG"] = str(v)
+        select(v)
         p, vf, _ = nn.infer_full(x, want_logits=False)
         outs[v] = (p.copy(), vf.copy())
     for v in variants[1:]:
