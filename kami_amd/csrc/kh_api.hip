@@ -143,21 +143,30 @@ uint16_t f2f16(float f)
 // holds W[co = ms*32 + r][k = 8h + j], j = 0..7) in consumption order tap -> k-step -> ms, BN scale
 // folded in before rounding, zero-padded to (MS*32, KS*16) and to a whole number of 8-fragment chunks.
 // ci0: first input channel of this pass (the 128-plane stem runs as two 64-channel passes).
+// centre_first: 3x3 taps in the order 4,0,1,2,3,5,6,7,8.  perm: the first `perm` k-steps of the
+// stream take their activations from the consumer's packed output registers (tower_mfma.hip,
+// packed_fragments): slot (h, j) of k-step ks is input channel
+// 32 (ks >> 1) + 8 (2 (ks & 1) + (j >> 2)) + 4 h + (j & 3) instead of 16 ks + 8 h + j.
 void pack_layer(std::vector<uint16_t>& out, int dtype, const float* w, const float* scale, int Co, int Ci,
-                int taps, int KS, int MS, int ci0 = 0)
+                int taps, int KS, int MS, int ci0 = 0, bool centre_first = false, int perm = 0)
 {
-    for (int tap = 0; tap < taps; ++tap)
-        for (int ks = 0; ks < KS; ++ks)
+    int kstep = 0;
+    for (int ti = 0; ti < taps; ++ti) {
+        const int tap = !centre_first ? ti : (ti == 0 ? 4 : (ti <= 4 ? ti - 1 : ti));
+        for (int ks = 0; ks < KS; ++ks, ++kstep)
             for (int ms = 0; ms < MS; ++ms)
                 for (int l = 0; l < 64; ++l) {
                     const int r = l & 31, h = l >> 5;
                     for (int j = 0; j < 8; ++j) {
-                        const int co = ms * 32 + r, ci = ci0 + ks * 16 + 8 * h + j;
+                        const int co = ms * 32 + r;
+                        const int ci = ci0 + (kstep < perm ? 32 * (ks >> 1) + 8 * (2 * (ks & 1) + (j >> 2)) + 4 * h + (j & 3)
+                                                           : ks * 16 + 8 * h + j);
                         float v = 0.0f;
                         if (co < Co && ci < Ci) v = w[((size_t)co * Ci + ci) * taps + tap] * (scale ? scale[co] : 1.0f);
                         out.push_back(dtype == KH_BF16 ? f2bf16(v) : f2f16(v));
                     }
                 }
+    }
     while (out.size() % 4096) out.push_back(0);
 }
 
@@ -258,15 +267,15 @@ int build_tower(Weights& W, const HostNet& n, int dtype, int F, int C, int R)
     memcpy(par.data(), sh.data(), sizeof(float) * C);
     for (int i = 0; i < 2 * R; ++i) {
         fold_bn(n.res[i], C, sc.data(), sh.data());
-        pack_layer(stream, dtype, n.res[i].w, sc.data(), C, C, 9, TW_CP / 16, 2);
+        pack_layer(stream, dtype, n.res[i].w, sc.data(), C, C, 9, TW_CP / 16, 2, 0, true, TW_CP / 16);
         memcpy(par.data() + (size_t)(1 + i) * TW_CP, sh.data(), sizeof(float) * C);
     }
     float* pshift1 = par.data() + (size_t)(1 + 2 * R) * TW_CP;
     fold_bn(n.pconv, KH_POLICY_MID, sc.data(), pshift1);
-    pack_layer(stream, dtype, n.pconv.w, sc.data(), KH_POLICY_MID, C, 1, TW_CP / 16, 4);
+    pack_layer(stream, dtype, n.pconv.w, sc.data(), KH_POLICY_MID, C, 1, TW_CP / 16, 4, 0, false, TW_CP / 16);
     float* pbias2 = pshift1 + KH_POLICY_MID;
     memcpy(pbias2, n.p2b, sizeof(float) * KH_POLICY_PLANES);
-    pack_layer(stream, dtype, n.p2w, nullptr, KH_POLICY_PLANES, KH_POLICY_MID, 1, KH_POLICY_MID / 16, 4);
+    pack_layer(stream, dtype, n.p2w, nullptr, KH_POLICY_PLANES, KH_POLICY_MID, 1, KH_POLICY_MID / 16, 4, 0, false, KH_POLICY_MID / 16);
     if (((stream.size() / 4096) & 1) != 0) stream.resize(stream.size() + 4096, 0);   // parity chunk (see gemm_dummy)
     float* vw = pbias2 + 128;
     float vs, vsh;

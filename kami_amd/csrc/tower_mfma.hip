@@ -201,12 +201,15 @@ template <int TAPS, int KS, int MS> struct LayerShape {
     static constexpr int NCH = (TK + KPC - 1) / KPC;         // chunks (the packer zero-pads the tail)
 };
 
-template <int TAPS, int KS>
+// CF (centre first): the 3x3 window is walked centre tap first, then the other eight in raster
+// order — the centre tap's operand is the wave's own previous output and comes from registers.
+template <int TAPS, int KS, bool CF = false>
 __device__ __forceinline__ constexpr unsigned b_offset(int kk, int stride)
 {
     // k-steps past the real ones multiply zero weights: point them at tap 0 (always in bounds)
     const int k = kk < TAPS * KS ? kk : 0;
-    const int tap = k / KS, ks = k % KS;
+    const int ti = k / KS, ks = k % KS;
+    const int tap = !CF ? ti : (ti == 0 ? 4 : (ti <= 4 ? ti - 1 : ti));
     return (unsigned)((TAPS == 9 ? ((tap / 3) * PITCH + (tap % 3)) * stride : 0) + ks * 32);
 }
 
@@ -214,18 +217,26 @@ struct NoHook { __device__ __forceinline__ void operator()() const {} };
 
 // RELAX / VMX: the first RELAX steps wait with VMX extra operations allowed in flight; hook() runs
 // between step HOOK_AT - 1 and step HOOK_AT.
-template <typename T, int TAPS, int KS, int MS, int PAR, int DBG = 0, int RELAX = 0, int VMX = 0, int HOOK_AT = -1, class Hook = NoHook>
+// NREG: the first NREG k-steps take their activation fragments from `breg` (the wave's own packed
+// output of the previous layer, see Packed) instead of the LDS image; CF as in b_offset.  With
+// NREG > 0 nothing is read from the image before the first step's barrier, which then also orders
+// the previous epilogue's image writes of all waves before the other taps' reads.
+template <typename T, int TAPS, int KS, int MS, int PAR, int DBG = 0, int RELAX = 0, int VMX = 0, int HOOK_AT = -1,
+          int NREG = 0, bool CF = false, class Hook = NoHook>
 __device__ __forceinline__ void gemm_layer(Pipe& p, const char* smem, int wave, int lane,
                                            unsigned b_base, int stride, f32x16 (&acc)[MS],
-                                           typename Elem<T>::vec8 (&A)[2][8], const Hook& hook = Hook())
+                                           typename Elem<T>::vec8 (&A)[2][8], const Hook& hook = Hook(),
+                                           const typename Elem<T>::vec8* breg = nullptr)
 {
     using V = typename Elem<T>::vec8;
     using S = LayerShape<TAPS, KS, MS>;
     constexpr int KPC = S::KPC;
     V B[2][KPC];
 #pragma unroll
-    for (int k = 0; k < KPC; ++k)
-        B[PAR][k] = *reinterpret_cast<const V*>(smem + b_base + b_offset<TAPS, KS>(k, stride));
+    for (int k = 0; k < KPC; ++k) {
+        if (k < NREG) B[PAR][k] = breg[k];
+        else B[PAR][k] = *reinterpret_cast<const V*>(smem + b_base + b_offset<TAPS, KS, CF>(k, stride));
+    }
 #pragma unroll
     for (int n = 0; n < S::NCH; ++n) {
         const int cur = (PAR + n) & 1, nxt = cur ^ 1;
@@ -241,8 +252,10 @@ __device__ __forceinline__ void gemm_layer(Pipe& p, const char* smem, int wave, 
             for (int k = 0; k < KPC; ++k) B[nxt][k] = B[cur][k];
         } else if (n + 1 < S::NCH) {
 #pragma unroll
-            for (int k = 0; k < KPC; ++k)
-                B[nxt][k] = *reinterpret_cast<const V*>(smem + b_base + b_offset<TAPS, KS>((n + 1) * KPC + k, stride));
+            for (int k = 0; k < KPC; ++k) {
+                if ((n + 1) * KPC + k < NREG) B[nxt][k] = breg[(n + 1) * KPC + k];
+                else B[nxt][k] = *reinterpret_cast<const V*>(smem + b_base + b_offset<TAPS, KS, CF>((n + 1) * KPC + k, stride));
+            }
         }
 #pragma unroll
         for (int k = 0; k < KPC; ++k)
@@ -291,18 +304,22 @@ __device__ __forceinline__ void acc_init(f32x16 (&acc)[MS], const float* shift, 
         }
 }
 
-// ReLU (+ skip added after it, nn.cpp:31), convert, 8-byte packed stores to the output image.
+// A wave's output tile after the epilogue, packed to T: o[ms][g] = channels 32 ms + 8 g + 4 h + 0..3
+// of this lane's pixel (the MFMA C/D layout: 4 consecutive channels per register group).
+template <int MS> struct Packed { u32x2 o[MS][4]; };
+
+// ReLU (+ the block's input added after it, nn.cpp:31) and convert.  The skip operand is the wave's
+// own packed tile of two layers ago: registers, not LDS.
 template <typename T, int MS, bool SKIP>
-__device__ __forceinline__ void conv_epilogue(const f32x16 (&acc)[MS], char* smem, unsigned out_pix, int h)
+__device__ __forceinline__ void epilogue_pack(const f32x16 (&acc)[MS], Packed<MS>& pk)
 {
 #pragma unroll
     for (int ms = 0; ms < MS; ++ms)
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
-            const unsigned addr = out_pix + (ms * 32 + 8 * g + 4 * h) * 2;
             u32x2 o;
             if (SKIP) {
-                const u32x2 old = *reinterpret_cast<const u32x2*>(smem + addr);
+                const u32x2 old = pk.o[ms][g];
                 o.x = pack2<T>(relu_nan(acc[ms][4 * g + 0]) + unpack_lo<T>(old.x), relu_nan(acc[ms][4 * g + 1]) + unpack_hi<T>(old.x));
                 o.y = pack2<T>(relu_nan(acc[ms][4 * g + 2]) + unpack_lo<T>(old.y), relu_nan(acc[ms][4 * g + 3]) + unpack_hi<T>(old.y));
             } else {
@@ -312,8 +329,34 @@ __device__ __forceinline__ void conv_epilogue(const f32x16 (&acc)[MS], char* sme
                 o.x = pack2<T>(relu_nan(acc[ms][4 * g + 0]), relu_nan(acc[ms][4 * g + 1]));
                 o.y = pack2<T>(relu_nan(acc[ms][4 * g + 2]), relu_nan(acc[ms][4 * g + 3]));
             }
-            *reinterpret_cast<u32x2*>(smem + addr) = o;
+            pk.o[ms][g] = o;
         }
+}
+
+// 8-byte packed stores of the tile to an LDS image (for the neighbouring pixels' taps).
+template <int MS>
+__device__ __forceinline__ void store_packed(const Packed<MS>& pk, char* smem, unsigned out_pix, int h)
+{
+#pragma unroll
+    for (int ms = 0; ms < MS; ++ms)
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+            *reinterpret_cast<u32x2*>(smem + out_pix + (ms * 32 + 8 * g + 4 * h) * 2) = pk.o[ms][g];
+}
+
+// The packed tile as MFMA B fragments: k-step ks, slot j of lane (r, h) = channel
+// 32 (ks >> 1) + 8 (2 (ks & 1) + (j >> 2)) + 4 h + (j & 3) — the packer orders the matching
+// weight fragments the same way (pack_layer, `perm`), so no data moves: two register pairs per k-step.
+template <typename T, int MS>
+__device__ __forceinline__ void packed_fragments(const Packed<MS>& pk, typename Elem<T>::vec8 (&b)[2 * MS])
+{
+    using V = typename Elem<T>::vec8;
+#pragma unroll
+    for (int ks = 0; ks < 2 * MS; ++ks) {
+        const u32x2 lo = pk.o[ks >> 1][2 * (ks & 1)], hi = pk.o[ks >> 1][2 * (ks & 1) + 1];
+        const u32x4 v = { lo.x, lo.y, hi.x, hi.y };
+        b[ks] = __builtin_bit_cast(V, v);
+    }
 }
 
 __device__ __forceinline__ float wave_max_f(float v)
@@ -413,7 +456,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     constexpr int SBOARD = NPIX * SSTR;
     constexpr int ST_SIZE = st_size(FP);
     constexpr int LDS_PAR = LDS_ST + ST_SIZE;
-    constexpr int LDS_P = LDS_ST + ST_SIZE - TW_NB * PBOARD;
     constexpr int LDS_L = LDS_X;
 
     const int tid = threadIdx.x;
@@ -440,8 +482,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     const unsigned sin = LDS_ST + wb * SBOARD + (py * PITCH + px) * SSTR + h * 16;
     const unsigned xout = LDS_X + wb * XBOARD + ((py + 1) * PITCH + px + 1) * XSTR;     // own pixel
     const unsigned tout = LDS_ST + wb * XBOARD + ((py + 1) * PITCH + px + 1) * XSTR;
-    const unsigned pout = LDS_P + wb * PBOARD + (py * 8 + px) * PSTR;
-    const unsigned pin = pout + h * 16;
 
     // Weight stream first: the ring fills while parameters and the first planes are fetched.
     Pipe pipe;
@@ -605,6 +645,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             lds_barrier();
         }
 
+        // This wave's tile of the residual stream (its own 32 pixels x 64 channels), packed: the skip
+        // operand, the centre-tap operand of the next conv and the input of both heads.  The LDS image
+        // X carries the same values for the neighbouring pixels' taps.
+        Packed<2> xk;
         // ---- 2. stem: conv1 + batchnorm1 + relu, S -> X                       nn.cpp:62-65
         {
             f32x16 acc[2];
@@ -620,7 +664,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             } else {
                 gemm_layer<T, 9, KS_STEM, 2, 0, DBG & 1024>(pipe, smem, wave, lane, sin, SSTR, acc, A);
             }
-            conv_epilogue<T, 2, false>(acc, smem, xout, h);
+            epilogue_pack<T, 2, false>(acc, xk);
+            store_packed<2>(xk, smem, xout, h);
             lds_barrier();
             // T shares LDS with S: clear T's halo before the tower reads through it
             const u32x4 z = { 0, 0, 0, 0 };
@@ -634,36 +679,44 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         }
 
         // ---- 3. residual tower: x = x + relu(bn2(conv2(relu(bn1(conv1 x)))))   nn.cpp:26-34
+        // Layer boundaries: the epilogue packs the tile, writes it to the image and the next conv
+        // starts on its centre tap from those registers; the first step's ring barrier doubles as the
+        // image barrier for the other eight taps.
         for (int r = 0; r < R; ++r) {
             f32x16 acc[2];
+            V bf[4];
+            packed_fragments<T, 2>(xk, bf);
             acc_init<2>(acc, shift3 + (1 + 2 * r) * TW_CP, h);
-            gemm_layer<T, 9, TW_CP / 16, 2, P1, DBG>(pipe, smem, wave, lane, xin, XSTR, acc, A);
-            conv_epilogue<T, 2, false>(acc, smem, tout, h);
-            lds_barrier();
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");          // own image writes done before the step barrier
+            gemm_layer<T, 9, TW_CP / 16, 2, P1, DBG, 0, 0, -1, 4, true>(pipe, smem, wave, lane, xin, XSTR, acc, A, NoHook(), bf);
+            Packed<2> tk;
+            epilogue_pack<T, 2, false>(acc, tk);
+            store_packed<2>(tk, smem, tout, h);
+            packed_fragments<T, 2>(tk, bf);
             acc_init<2>(acc, shift3 + (2 + 2 * r) * TW_CP, h);
-            gemm_layer<T, 9, TW_CP / 16, 2, P1 ^ 1, DBG>(pipe, smem, wave, lane, tin, XSTR, acc, A);
-            conv_epilogue<T, 2, true>(acc, smem, xout, h);
-            lds_barrier();
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            gemm_layer<T, 9, TW_CP / 16, 2, P1 ^ 1, DBG, 0, 0, -1, 4, true>(pipe, smem, wave, lane, tin, XSTR, acc, A, NoHook(), bf);
+            epilogue_pack<T, 2, true>(acc, xk);
+            store_packed<2>(xk, smem, xout, h);
         }
 
-        // ---- 4a. value head, first half: valueconv + vbatchnorm + relu          nn.cpp:83-85
-        if (tid < TW_NB * 64) {
-            const int bb = tid >> 6, p = tid & 63;
-            const char* xp = smem + LDS_X + bb * XBOARD + (((p >> 3) + 1) * PITCH + (p & 7) + 1) * XSTR;
-            float s = 0.0f, chk = 0.0f;
+        // ---- 4a. value head, first half: valueconv + vbatchnorm + relu (nn.cpp:83-85) from the packed
+        //          tile: each lane holds 32 of its pixel's 64 channels, its partner lane (+32) the rest
+        {
+            float sv = 0.0f, chk = 0.0f;
 #pragma unroll
-            for (int k = 0; k < TW_CP / 8; ++k) {
-                const u32x4 u = *reinterpret_cast<const u32x4*>(xp + k * 16);
-                const float* w = vw + k * 8;
-                // x * 0 is NaN exactly when x is NaN or Inf: poisoned residual stream detector
-                chk = fmaf(unpack_lo<T>(u.x) + unpack_hi<T>(u.x) + unpack_lo<T>(u.y) + unpack_hi<T>(u.y), 0.0f, chk);
-                chk = fmaf(unpack_lo<T>(u.z) + unpack_hi<T>(u.z) + unpack_lo<T>(u.w) + unpack_hi<T>(u.w), 0.0f, chk);
-                s = fmaf(unpack_lo<T>(u.x), w[0], s); s = fmaf(unpack_hi<T>(u.x), w[1], s);
-                s = fmaf(unpack_lo<T>(u.y), w[2], s); s = fmaf(unpack_hi<T>(u.y), w[3], s);
-                s = fmaf(unpack_lo<T>(u.z), w[4], s); s = fmaf(unpack_hi<T>(u.z), w[5], s);
-                s = fmaf(unpack_lo<T>(u.w), w[6], s); s = fmaf(unpack_hi<T>(u.w), w[7], s);
-            }
-            v64[bb * 64 + p] = relu_nan(s + vsh[0]);
+            for (int ms = 0; ms < 2; ++ms)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const float4 w = *reinterpret_cast<const float4*>(vw + ms * 32 + 8 * g + 4 * h);
+                    const u32x2 o = xk.o[ms][g];
+                    const float x0 = unpack_lo<T>(o.x), x1 = unpack_hi<T>(o.x), x2 = unpack_lo<T>(o.y), x3 = unpack_hi<T>(o.y);
+                    // x * 0 is NaN exactly when x is NaN or Inf: poisoned residual stream detector
+                    chk = fmaf((x0 + x1) + (x2 + x3), 0.0f, chk);
+                    sv = fmaf(x0, w.x, sv); sv = fmaf(x1, w.y, sv); sv = fmaf(x2, w.z, sv); sv = fmaf(x3, w.w, sv);
+                }
+            sv += __shfl_xor(sv, 32, 64);
+            if (h == 0) v64[wb * 64 + py * 8 + px] = relu_nan(sv + vsh[0]);
             if (chk != chk) atomicOr(&a.flags[0], 1);
         }
 
@@ -675,22 +728,27 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         const float fcbias = a.fcb[tid];
         __builtin_amdgcn_sched_barrier(0);
 
-        // ---- 4b. policy head: policyconv + pbatchnorm + relu, X -> P (128 ch)   nn.cpp:72-74
+        // ---- 4b. policy head: policyconv + pbatchnorm + relu (nn.cpp:72-74), 1x1: the operand is the
+        //          wave's own tile, and so is policyconv2's — neither touches an LDS image
+        Packed<4> pk;
         {
             f32x16 acc[4];
+            V bf[4];
+            packed_fragments<T, 2>(xk, bf);
             acc_init<4>(acc, pshift1, h);
-            gemm_layer<T, 1, TW_CP / 16, 4, P1, DBG & 1024, 2, 17>(pipe, smem, wave, lane, xin + (PITCH + 1) * XSTR, XSTR, acc, A);
-            conv_epilogue<T, 4, false>(acc, smem, pout, h);
-            lds_barrier();
+            gemm_layer<T, 1, TW_CP / 16, 4, P1, DBG & 1024, 2, 17, -1, 4>(pipe, smem, wave, lane, 0, 0, acc, A, NoHook(), bf);
+            epilogue_pack<T, 4, false>(acc, pk);
         }
         // ---- 4e'. (timing variant) value FC before the policy steps: +0.13 us
         if ((DBG & 2048) && !(DBG & 256)) value_fc(a, fcw, fcbias, v64, b0, tid, lane);
 
-        // ---- 4c. policyconv2 (+bias): P -> logits L[board][pixel*73 + plane]    nn.cpp:75-79
+        // ---- 4c. policyconv2 (+bias): -> logits L[board][pixel*73 + plane]      nn.cpp:75-79
         {
             f32x16 acc[4];                  // 73 planes padded to 128 rows: whole 2-k-step chunks
+            V bf[8];
+            packed_fragments<T, 4>(pk, bf);
             acc_init<4>(acc, pbias2, h);
-            gemm_layer<T, 1, KH_POLICY_MID / 16, 4, P1, DBG & 1024, RING_D - 4, 17>(pipe, smem, wave, lane, pin, PSTR, acc, A);
+            gemm_layer<T, 1, KH_POLICY_MID / 16, 4, P1, DBG & 1024, RING_D - 4, 17, -1, 8>(pipe, smem, wave, lane, 0, 0, acc, A, NoHook(), bf);
             if (P1) gemm_dummy<T, 1>(pipe, smem, wave, lane, A);      // stream parity back to 0 for the next group
             float* lrow = reinterpret_cast<float*>(smem + LDS_L + wb * LBOARD) + (py * 8 + px) * KH_POLICY_PLANES;
             if (!(DBG & 4096)) {    // raw logits to LDS, softmax below
