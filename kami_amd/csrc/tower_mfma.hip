@@ -85,20 +85,15 @@ template <> struct Elem<_Float16> {
     static __device__ __forceinline__ f32x16 mfma(vec8 a, vec8 b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0); }
 };
 
-// Two fp32 -> one dword of two T (round to nearest even), ONE instruction.  hipcc does not form the
-// packed convert from scalar casts + shifts here (it emits cvt, shift, or per pair), so it is asm.
-template <typename T> __device__ __forceinline__ unsigned pack2(float lo, float hi);
-template <> __device__ __forceinline__ unsigned pack2<__bf16>(float lo, float hi)
+// Two fp32 -> one dword of two T (round to nearest even): the vector convert lowers to ONE
+// v_cvt_pk_bf16_f32 / v_cvt_pk_f16_f32 on gfx950 (scalar casts + shifts do not), and being
+// compiler-visible it gets its MFMA-result read hazards padded like any other VALU op.
+using f32x2 = float __attribute__((ext_vector_type(2)));
+template <typename T> __device__ __forceinline__ unsigned pack2(float lo, float hi)
 {
-    unsigned r;
-    asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(lo), "v"(hi));
-    return r;
-}
-template <> __device__ __forceinline__ unsigned pack2<_Float16>(float lo, float hi)
-{
-    unsigned r;
-    asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(r) : "v"(lo), "v"(hi));
-    return r;
+    using T2 = T __attribute__((ext_vector_type(2)));
+    const f32x2 v = { lo, hi };
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(v, T2));
 }
 // ReLU on a packed pair of bf16 / f16: both formats keep the sign in bit 15, so a signed 16-bit
 // max with 0 clears negatives (and -0) and leaves everything else: one v_pk_max_i16 per 2 values.
@@ -308,29 +303,38 @@ __device__ __forceinline__ void acc_init(f32x16 (&acc)[MS], const float* shift, 
 // of this lane's pixel (the MFMA C/D layout: 4 consecutive channels per register group).
 template <int MS> struct Packed { u32x2 o[MS][4]; };
 
-// ReLU (+ the block's input added after it, nn.cpp:31) and convert.  The skip operand is the wave's
-// own packed tile of two layers ago: registers, not LDS.
-template <typename T, int MS, bool SKIP>
+// ReLU and convert (conv1 of a block, policyconv): convert first, then ReLU on the packed pairs —
+// half the VALU work of clamping the 32 fp32 values.
+template <typename T, int MS>
 __device__ __forceinline__ void epilogue_pack(const f32x16 (&acc)[MS], Packed<MS>& pk)
 {
 #pragma unroll
     for (int ms = 0; ms < MS; ++ms)
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
-            u32x2 o;
-            if (SKIP) {
-                const u32x2 old = pk.o[ms][g];
-                o.x = pack2<T>(relu_nan(acc[ms][4 * g + 0]) + unpack_lo<T>(old.x), relu_nan(acc[ms][4 * g + 1]) + unpack_hi<T>(old.x));
-                o.y = pack2<T>(relu_nan(acc[ms][4 * g + 2]) + unpack_lo<T>(old.y), relu_nan(acc[ms][4 * g + 3]) + unpack_hi<T>(old.y));
-            } else {
-                // relu_nan first: it is compiler-visible, so hipcc pads the MFMA-result -> VALU-read
-                // hazard for it; the asm convert then only ever reads VALU results (hipcc cannot
-                // see into an asm statement and would not pad an MFMA -> asm dependency)
-                o.x = pack2<T>(relu_nan(acc[ms][4 * g + 0]), relu_nan(acc[ms][4 * g + 1]));
-                o.y = pack2<T>(relu_nan(acc[ms][4 * g + 2]), relu_nan(acc[ms][4 * g + 3]));
-            }
-            pk.o[ms][g] = o;
+            pk.o[ms][g].x = relu_pk(pack2<T>(acc[ms][4 * g + 0], acc[ms][4 * g + 1]));
+            pk.o[ms][g].y = relu_pk(pack2<T>(acc[ms][4 * g + 2], acc[ms][4 * g + 3]));
         }
+}
+
+// End of a residual block (and the stem): xf = (SKIP ? xf : 0) + relu(acc) in fp32 — the residual
+// stream of the wave's own pixels stays in fp32 registers (nn.cpp:31 adds in fp32 too), only the
+// copies that feed the MFMAs are rounded to T.
+template <typename T, bool SKIP>
+__device__ __forceinline__ void epilogue_residual(const f32x16 (&acc)[2], f32x16 (&xf)[2], Packed<2>& pk)
+{
+#pragma unroll
+    for (int ms = 0; ms < 2; ++ms) {
+        f32x16 t;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) t[i] = relu_nan(acc[ms][i]);
+        xf[ms] = SKIP ? xf[ms] + t : t;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            pk.o[ms][g].x = pack2<T>(xf[ms][4 * g + 0], xf[ms][4 * g + 1]);
+            pk.o[ms][g].y = pack2<T>(xf[ms][4 * g + 2], xf[ms][4 * g + 3]);
+        }
+    }
 }
 
 // 8-byte packed stores of the tile to an LDS image (for the neighbouring pixels' taps).
@@ -649,6 +653,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         // operand, the centre-tap operand of the next conv and the input of both heads.  The LDS image
         // X carries the same values for the neighbouring pixels' taps.
         Packed<2> xk;
+        f32x16 xf[2];          // the same tile in fp32: the skip operand and the value head's input
         // ---- 2. stem: conv1 + batchnorm1 + relu, S -> X                       nn.cpp:62-65
         {
             f32x16 acc[2];
@@ -664,7 +669,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             } else {
                 gemm_layer<T, 9, KS_STEM, 2, 0, DBG & 1024>(pipe, smem, wave, lane, sin, SSTR, acc, A);
             }
-            epilogue_pack<T, 2, false>(acc, xk);
+            epilogue_residual<T, false>(acc, xf, xk);
             store_packed<2>(xk, smem, xout, h);
             lds_barrier();
             // T shares LDS with S: clear T's halo before the tower reads through it
@@ -690,17 +695,17 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");          // own image writes done before the step barrier
             gemm_layer<T, 9, TW_CP / 16, 2, P1, DBG, 0, 0, -1, 4, true>(pipe, smem, wave, lane, xin, XSTR, acc, A, NoHook(), bf);
             Packed<2> tk;
-            epilogue_pack<T, 2, false>(acc, tk);
+            epilogue_pack<T, 2>(acc, tk);
             store_packed<2>(tk, smem, tout, h);
             packed_fragments<T, 2>(tk, bf);
             acc_init<2>(acc, shift3 + (2 + 2 * r) * TW_CP, h);
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             gemm_layer<T, 9, TW_CP / 16, 2, P1 ^ 1, DBG, 0, 0, -1, 4, true>(pipe, smem, wave, lane, tin, XSTR, acc, A, NoHook(), bf);
-            epilogue_pack<T, 2, true>(acc, xk);
+            epilogue_residual<T, true>(acc, xf, xk);
             store_packed<2>(xk, smem, xout, h);
         }
 
-        // ---- 4a. value head, first half: valueconv + vbatchnorm + relu (nn.cpp:83-85) from the packed
+        // ---- 4a. value head, first half: valueconv + vbatchnorm + relu (nn.cpp:83-85) on the fp32
         //          tile: each lane holds 32 of its pixel's 64 channels, its partner lane (+32) the rest
         {
             float sv = 0.0f, chk = 0.0f;
@@ -709,8 +714,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
                     const float4 w = *reinterpret_cast<const float4*>(vw + ms * 32 + 8 * g + 4 * h);
-                    const u32x2 o = xk.o[ms][g];
-                    const float x0 = unpack_lo<T>(o.x), x1 = unpack_hi<T>(o.x), x2 = unpack_lo<T>(o.y), x3 = unpack_hi<T>(o.y);
+                    const float x0 = xf[ms][4 * g], x1 = xf[ms][4 * g + 1], x2 = xf[ms][4 * g + 2], x3 = xf[ms][4 * g + 3];
                     // x * 0 is NaN exactly when x is NaN or Inf: poisoned residual stream detector
                     chk = fmaf((x0 + x1) + (x2 + x3), 0.0f, chk);
                     sv = fmaf(x0, w.x, sv); sv = fmaf(x1, w.y, sv); sv = fmaf(x2, w.z, sv); sv = fmaf(x3, w.w, sv);
@@ -737,7 +741,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             packed_fragments<T, 2>(xk, bf);
             acc_init<4>(acc, pshift1, h);
             gemm_layer<T, 1, TW_CP / 16, 4, P1, DBG & 1024, 2, 17, -1, 4>(pipe, smem, wave, lane, 0, 0, acc, A, NoHook(), bf);
-            epilogue_pack<T, 4, false>(acc, pk);
+            epilogue_pack<T, 4>(acc, pk);
         }
         // ---- 4e'. (timing variant) value FC before the policy steps: +0.13 us
         if ((DBG & 2048) && !(DBG & 256)) value_fc(a, fcw, fcbias, v64, b0, tid, lane);
