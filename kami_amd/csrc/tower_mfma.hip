@@ -208,6 +208,15 @@ __device__ __forceinline__ constexpr unsigned b_offset(int kk, int stride)
     return (unsigned)((TAPS == 9 ? ((tap / 3) * PITCH + (tap % 3)) * stride : 0) + ks * 32);
 }
 
+// (DBG 1024) extra stamp inside a layer boundary: slot b, point k
+__device__ __forceinline__ void bstamp(Pipe& p, int wave, int lane, int b, int k)
+{
+    __builtin_amdgcn_sched_barrier(0);
+    const unsigned long long t = __builtin_amdgcn_s_memtime();
+    if (p.stamps && lane == 0 && b < 64) p.stamps[4 * 256 * 3 + ((size_t)wave * 64 + b) * 4 + k] = t;
+    __builtin_amdgcn_sched_barrier(0);
+}
+
 struct NoHook { __device__ __forceinline__ void operator()() const {} };
 
 // RELAX / VMX: the first RELAX steps wait with VMX extra operations allowed in flight; hook() runs
@@ -217,7 +226,7 @@ struct NoHook { __device__ __forceinline__ void operator()() const {} };
 // NREG > 0 nothing is read from the image before the first step's barrier, which then also orders
 // the previous epilogue's image writes of all waves before the other taps' reads.
 template <typename T, int TAPS, int KS, int MS, int PAR, int DBG = 0, int RELAX = 0, int VMX = 0, int HOOK_AT = -1,
-          int NREG = 0, bool CF = false, class Hook = NoHook>
+          int NREG = 0, bool CF = false, int TAILV = 0, class Hook = NoHook>
 __device__ __forceinline__ void gemm_layer(Pipe& p, const char* smem, int wave, int lane,
                                            unsigned b_base, int stride, f32x16 (&acc)[MS],
                                            typename Elem<T>::vec8 (&A)[2][8], const Hook& hook = Hook(),
@@ -251,6 +260,25 @@ __device__ __forceinline__ void gemm_layer(Pipe& p, const char* smem, int wave, 
                 if ((n + 1) * KPC + k < NREG) B[nxt][k] = breg[(n + 1) * KPC + k];
                 else B[nxt][k] = *reinterpret_cast<const V*>(smem + b_base + b_offset<TAPS, KS, CF>((n + 1) * KPC + k, stride));
             }
+        }
+        if (TAILV > 0 && n == S::NCH - 1) {
+            // last chunk, tile-major: tile 0 is final four MFMAs early and the caller's epilogue of
+            // it (TAILV vector ops per MFMA gap) runs under tile 1's MFMAs
+#pragma unroll
+            for (int ms = 0; ms < MS; ++ms)
+#pragma unroll
+                for (int k = 0; k < KPC; ++k) acc[ms] = Elem<T>::mfma(A[cur][k * MS + ms], B[cur][k], acc[ms]);
+#pragma unroll
+            for (int i = 0; i < KPC; ++i) {
+                __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);   // DS read (next layer's first weights)
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // MFMA tile 0
+            }
+#pragma unroll
+            for (int i = 0; i < (MS - 1) * KPC; ++i) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // MFMA tile 1..
+                if (i > 0) __builtin_amdgcn_sched_group_barrier(0x002, TAILV, 0);   // VALU: tile 0's epilogue
+            }
+            continue;
         }
 #pragma unroll
         for (int k = 0; k < KPC; ++k)
@@ -309,12 +337,22 @@ template <typename T, int MS>
 __device__ __forceinline__ void epilogue_pack(const f32x16 (&acc)[MS], Packed<MS>& pk)
 {
 #pragma unroll
-    for (int ms = 0; ms < MS; ++ms)
+    for (int ms = 0; ms < MS; ++ms) {
+        // all eight converts of a tile, then all eight clamps: left alone hipcc alternates them
+        // through one temporary register and every instruction waits for the one before it
+        unsigned c[8];
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
-            pk.o[ms][g].x = relu_pk(pack2<T>(acc[ms][4 * g + 0], acc[ms][4 * g + 1]));
-            pk.o[ms][g].y = relu_pk(pack2<T>(acc[ms][4 * g + 2], acc[ms][4 * g + 3]));
+            c[2 * g] = pack2<T>(acc[ms][4 * g + 0], acc[ms][4 * g + 1]);
+            c[2 * g + 1] = pack2<T>(acc[ms][4 * g + 2], acc[ms][4 * g + 3]);
         }
+        asm volatile("" : "+v"(c[0]), "+v"(c[1]), "+v"(c[2]), "+v"(c[3]), "+v"(c[4]), "+v"(c[5]), "+v"(c[6]), "+v"(c[7]));
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            pk.o[ms][g].x = relu_pk(c[2 * g]);
+            pk.o[ms][g].y = relu_pk(c[2 * g + 1]);
+        }
+    }
 }
 
 // End of a residual block (and the stem): xf = (SKIP ? xf : 0) + relu(acc) in fp32 — the residual
@@ -687,48 +725,80 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         // Layer boundaries: the epilogue packs the tile, writes it to the image and the next conv
         // starts on its centre tap from those registers; the first step's ring barrier doubles as the
         // image barrier for the other eight taps.
+        f32x16 accn[2];         // next layer's accumulator start (its folded shifts), fetched a layer ahead
+        acc_init<2>(accn, shift3 + TW_CP, h);
         for (int r = 0; r < R; ++r) {
             f32x16 acc[2];
             V bf[4];
             packed_fragments<T, 2>(xk, bf);
-            acc_init<2>(acc, shift3 + (1 + 2 * r) * TW_CP, h);
+            acc[0] = accn[0]; acc[1] = accn[1];
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");          // own image writes done before the step barrier
-            gemm_layer<T, 9, TW_CP / 16, 2, P1, DBG, 0, 0, -1, 4, true>(pipe, smem, wave, lane, xin, XSTR, acc, A, NoHook(), bf);
+            acc_init<2>(accn, shift3 + (2 + 2 * r) * TW_CP, h);
+            gemm_layer<T, 9, TW_CP / 16, 2, P1, DBG, 0, 0, -1, 4, true, (DBG & 8192) ? 0 : 6>(pipe, smem, wave, lane, xin, XSTR, acc, A, NoHook(), bf);
             Packed<2> tk;
+            if (DBG & 1024) bstamp(pipe, wave, lane, 2 * r, 0);
+            if (DBG & 16384) {          // (timing variant) the epilogue arithmetic twice
+                epilogue_pack<T, 2>(acc, tk);
+#pragma unroll
+                for (int ms = 0; ms < 2; ++ms) asm volatile("" : "+v"(acc[ms]), "+v"(tk.o[ms][0]), "+v"(tk.o[ms][1]), "+v"(tk.o[ms][2]), "+v"(tk.o[ms][3]));
+            }
             epilogue_pack<T, 2>(acc, tk);
+            if (DBG & 32768) { store_packed<2>(tk, smem, tout, h); asm volatile("" ::: "memory"); }
+            if (DBG & 65536) lds_barrier();
             store_packed<2>(tk, smem, tout, h);
+            if (DBG & 1024) bstamp(pipe, wave, lane, 2 * r, 1);
             packed_fragments<T, 2>(tk, bf);
-            acc_init<2>(acc, shift3 + (2 + 2 * r) * TW_CP, h);
+            acc[0] = accn[0]; acc[1] = accn[1];
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            gemm_layer<T, 9, TW_CP / 16, 2, P1 ^ 1, DBG, 0, 0, -1, 4, true>(pipe, smem, wave, lane, tin, XSTR, acc, A, NoHook(), bf);
+            if (DBG & 1024) bstamp(pipe, wave, lane, 2 * r, 2);
+            acc_init<2>(accn, shift3 + (3 + 2 * r) * TW_CP, h);         // (past the last block: the policy shifts, unused)
+            gemm_layer<T, 9, TW_CP / 16, 2, P1 ^ 1, DBG, 0, 0, -1, 4, true, (DBG & 8192) ? 0 : 11>(pipe, smem, wave, lane, tin, XSTR, acc, A, NoHook(), bf);
+            if (DBG & 1024) bstamp(pipe, wave, lane, 2 * r + 1, 0);
+            if (DBG & 16384) {
+                f32x16 xf2[2] = { xf[0], xf[1] };
+                epilogue_residual<T, true>(acc, xf2, xk);
+#pragma unroll
+                for (int ms = 0; ms < 2; ++ms) asm volatile("" : "+v"(acc[ms]), "+v"(xf[ms]), "+v"(xk.o[ms][0]), "+v"(xk.o[ms][1]), "+v"(xk.o[ms][2]), "+v"(xk.o[ms][3]), "+v"(xf2[ms]));
+            }
             epilogue_residual<T, true>(acc, xf, xk);
+            if (DBG & 32768) { store_packed<2>(xk, smem, xout, h); asm volatile("" ::: "memory"); }
+            if (DBG & 65536) lds_barrier();
             store_packed<2>(xk, smem, xout, h);
+            if (DBG & 1024) bstamp(pipe, wave, lane, 2 * r + 1, 1);
         }
 
         // ---- 4a. value head, first half: valueconv + vbatchnorm + relu (nn.cpp:83-85) on the fp32
-        //          tile: each lane holds 32 of its pixel's 64 channels, its partner lane (+32) the rest
+        //          tile: each lane holds 32 of its pixel's 64 channels, its partner lane (+-32) the rest.
+        //          Four independent partial sums (a single fma chain is latency-bound with one wave per
+        //          SIMD), halves joined by one v_permlane32_swap.  A NaN or Inf anywhere in the residual
+        //          stream makes this lane's partial sum non-finite (x*w, w finite): that is the poisoned-
+        //          stream detector for the ReLUs' NaN squashing (see relu_nan).
         {
-            float sv = 0.0f, chk = 0.0f;
+            f32x2 s01 = { 0.0f, 0.0f }, s23 = { 0.0f, 0.0f };      // register pairs: v_pk_fma_f32 on consecutive registers
 #pragma unroll
             for (int ms = 0; ms < 2; ++ms)
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
-                    const float4 w = *reinterpret_cast<const float4*>(vw + ms * 32 + 8 * g + 4 * h);
-                    const float x0 = xf[ms][4 * g], x1 = xf[ms][4 * g + 1], x2 = xf[ms][4 * g + 2], x3 = xf[ms][4 * g + 3];
-                    // x * 0 is NaN exactly when x is NaN or Inf: poisoned residual stream detector
-                    chk = fmaf((x0 + x1) + (x2 + x3), 0.0f, chk);
-                    sv = fmaf(x0, w.x, sv); sv = fmaf(x1, w.y, sv); sv = fmaf(x2, w.z, sv); sv = fmaf(x3, w.w, sv);
+                    using f32x4 = float __attribute__((ext_vector_type(4)));
+                    const f32x4 w = *reinterpret_cast<const f32x4*>(vw + ms * 32 + 8 * g + 4 * h);
+                    const f32x2 x01 = { xf[ms][4 * g + 0], xf[ms][4 * g + 1] }, x23 = { xf[ms][4 * g + 2], xf[ms][4 * g + 3] };
+                    s01 = x01 * w.xy + s01;
+                    s23 = x23 * w.zw + s23;
                 }
-            sv += __shfl_xor(sv, 32, 64);
+            const float part = (s01.x + s01.y) + (s23.x + s23.y);
+            const unsigned pu = __float_as_uint(part);
+            if ((pu & 0x7f800000u) == 0x7f800000u) atomicOr(&a.flags[0], 1);
+            const auto sw = __builtin_amdgcn_permlane32_swap(pu, pu, false, false);   // {lanes 0-31 twice, lanes 32-63 twice}
+            const float sv = __uint_as_float(sw[0]) + __uint_as_float(sw[1]);
             if (h == 0) v64[wb * 64 + py * 8 + px] = relu_nan(sv + vsh[0]);
-            if (chk != chk) atomicOr(&a.flags[0], 1);
         }
 
         // valuefc row of this thread (output j = tid): requested here, used after the softmax.  17 loads
         // younger than the ring's: the next RING_D - 2 steps (two of 4b, two of 4c) leave them in flight.
         float4 fcw[16];
 #pragma unroll
-        for (int k = 0; k < 16; ++k) fcw[k] = reinterpret_cast<const float4*>(a.fcw4)[k * KH_VALUE_WIDTH + tid];
+        for (int k = 0; k < 16; ++k)      // scalar base + one lane offset: no per-load address registers
+            fcw[k] = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(a.fcw4) + (size_t)k * KH_VALUE_WIDTH * 16 + (unsigned)tid * 16u);
         const float fcbias = a.fcb[tid];
         __builtin_amdgcn_sched_barrier(0);
 
@@ -952,6 +1022,11 @@ hipError_t launch_tower(int dtype, int FP, const TowerArgs& a, int num_cus, hipS
         case 2048: return launch<__bf16, 8, 2048>(a, grid, s);
         case 4096: return launch<__bf16, 8, 4096>(a, grid, s);
         case 6144: return launch<__bf16, 8, 6144>(a, grid, s);
+        case 8192: return launch<__bf16, 8, 8192>(a, grid, s);
+        case 16384: return launch<__bf16, 8, 16384>(a, grid, s);
+        case 32768: return launch<__bf16, 8, 32768>(a, grid, s);
+        case 65536: return launch<__bf16, 8, 65536>(a, grid, s);
+        case 114688: return launch<__bf16, 8, 114688>(a, grid, s);
         default: break;
         }
     }
