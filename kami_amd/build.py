@@ -81,7 +81,26 @@ def build_all(force: bool = False, verbose: bool = False) -> str:
         rt = _hip_runtime_dir()
         run(["g++", "-shared", "-o", LIB] + objs +
             [f"-L{rt}", "-lamdhip64", f"-Wl,-rpath,{rt}", "-lpthread"])
+    build_search(force or bool(jobs), verbose)
     return LIB
+
+
+SEARCH_LIB = os.path.join(HERE, "libkamisearch.so")
+
+
+def build_search(force: bool = False, verbose: bool = False) -> str:
+    """libkamisearch.so: the host side that feeds the engine (rules, MCTS, self-play pool; include/kami_search.h).
+    Plain C++, linked against libkamihip.so for kh_encode_infer_legal."""
+    host = os.path.join(HERE, "host")
+    srcs = [os.path.join(host, f) for f in ("search_api.cpp", "mcts.h", "env.h", "chess.h")]
+    srcs += [os.path.join(os.path.dirname(HERE), "include", f) for f in ("kami_search.h", "kami_hip.h")]
+    if force or _stale(SEARCH_LIB, srcs + [LIB]):
+        cmd = ["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-Wall", "-o", SEARCH_LIB, srcs[0],
+               f"-L{HERE}", "-lkamihip", "-Wl,-rpath,$ORIGIN", "-lpthread"]
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        subprocess.check_call(cmd)
+    return SEARCH_LIB
 
 
 if __name__ == "__main__":

@@ -1,0 +1,346 @@
+// search_api.cpp — libkamisearch.so: C ABI over env.h / mcts.h and the self-play pool that feeds the
+// engine (include/kami_search.h).  Host code only; the one device entry point it uses is
+// kh_encode_infer_legal.
+#include "../../include/kami_search.h"
+#include "mcts.h"
+
+#include <atomic>
+#include <chrono>
+#include <cstdarg>
+#include <cstdio>
+#include <mutex>
+#include <string>
+#include <thread>
+
+using namespace kami;
+
+namespace {
+thread_local std::string g_err;
+int fail(const char* fmt, ...)
+{
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    g_err = buf;
+    return 1;
+}
+
+// the synthetic evaluator of the reference harness (`kami_ref mcts`, test infrastructure)
+uint64_t fnv1a(const std::string& s)
+{
+    uint64_t h = 1469598103934665603ull;
+    for (unsigned char c : s) { h ^= c; h *= 1099511628211ull; }
+    return h;
+}
+uint64_t splitmix(uint64_t x)
+{
+    x += 0x9e3779b97f4a7c15ull;
+    x = (x ^ (x >> 30)) * 0xbf58476d1ce4e5b9ull;
+    x = (x ^ (x >> 27)) * 0x94d049bb133111ebull;
+    return x ^ (x >> 31);
+}
+}  // namespace
+
+extern "C" {
+
+const char* ks_last_error(void) { return g_err.c_str(); }
+
+int ks_perft(const char* fen, int depth, uint64_t* nodes)
+{
+    chess::Position p;
+    if (!chess::Position::from_fen(fen, p)) return fail("bad FEN");
+    *nodes = chess::perft(p, depth);
+    return 0;
+}
+
+int ks_fen_actions(const char* fen, int32_t* out, int cap)
+{
+    chess::Position p;
+    if (!chess::Position::from_fen(fen, p)) { fail("bad FEN"); return -1; }
+    chess::Move mv[chess::MAX_MOVES];
+    const int n = p.legal(mv);
+    std::vector<int> a;
+    for (int i = 0; i < n; ++i) a.push_back(chess::encode_action(p, mv[i]));
+    std::sort(a.begin(), a.end());
+    for (int i = 0; i < n && i < cap; ++i) out[i] = a[i];
+    return n;
+}
+
+struct ks_env { Env env; };
+ks_env* ks_env_new(void) { return new ks_env(); }
+void ks_env_free(ks_env* e) { delete e; }
+int ks_env_ply(ks_env* e) { return e->env.ply(); }
+int ks_env_actions(ks_env* e, int32_t* out, int cap)
+{
+    const std::vector<int>& a = e->env.actions();
+    for (size_t i = 0; i < a.size() && (int)i < cap; ++i) out[i] = a[i];
+    return (int)a.size();
+}
+int ks_env_push(ks_env* e, int action)
+{
+    bool legal = false;
+    for (int a : e->env.actions()) legal |= a == action;
+    if (!legal) return fail("action %d is not legal here", action);
+    e->env.push(action);
+    return 0;
+}
+int ks_env_pop(ks_env* e)
+{
+    if (e->env.ply() == 0) return fail("pop at the initial position");
+    e->env.pop();
+    return 0;
+}
+int ks_env_terminal(ks_env* e, float* value) { return e->env.terminal(value) ? 1 : 0; }
+float ks_env_turn(ks_env* e) { return e->env.turn(); }
+int ks_env_fen(ks_env* e, char* buf, int cap)
+{
+    const std::string s = e->env.print();
+    snprintf(buf, cap, "%s", s.c_str());
+    return (int)s.size();
+}
+void ks_env_record(ks_env* e, kh_board* out) { e->env.record(out); }
+
+int ks_mcts_synthetic(int nodes, int nmoves, int leaves, const int32_t* picks, int npicks, char* out, int cap)
+{
+    try {
+        MCTSConfig cfg;
+        cfg.mcts_noise_weight = 0.0f;
+        MCTS tree(cfg);
+        std::string text;
+        char line[256];
+        std::vector<float> policy(PSIZE);
+        std::vector<MCTS::Leaf> batch((size_t)(leaves > 1 ? leaves : 1));
+        for (int m = 0; m < nmoves; ++m) {
+            while (tree.n() < nodes) {
+                // up to `leaves` positions in flight, never more than the visits still missing
+                int nb = 0;
+                while (nb < (int)batch.size() && tree.n() + nb < nodes) {
+                    bool blocked = false;
+                    if (tree.select_leaf(&batch[nb], &blocked)) ++nb;
+                    else if (blocked) break;
+                    else if (tree.n() + nb >= nodes) break;         // a terminal visit was counted
+                }
+                for (int j = 0; j < nb; ++j) {
+                    // the evaluator sees the leaf position: rebuild its FEN by replaying the path
+                    std::vector<int> path;
+                    for (Node* x = batch[j].node; x->parent; x = x->parent) path.push_back(x->action);
+                    Env& e = tree.get_env();
+                    for (auto it = path.rbegin(); it != path.rend(); ++it) e.push(*it);
+                    const uint64_t h = fnv1a(e.print());
+                    for (size_t k = 0; k < path.size(); ++k) e.pop();
+                    double sum = 0.0;
+                    for (int a = 0; a < PSIZE; ++a) { policy[a] = (float)(splitmix(h + (uint64_t)a) % 16777213ull + 1); sum += policy[a]; }
+                    for (int a = 0; a < PSIZE; ++a) policy[a] = (float)(policy[a] / sum);
+                    const float value = ((float)(splitmix(h ^ 0x7777) % 2001) - 1000.0f) / 1000.0f;
+                    float ptotal = 0.0f;
+                    for (int a : batch[j].actions) ptotal += policy[a];
+                    std::vector<float> pr(batch[j].actions.size());
+                    for (size_t i = 0; i < pr.size(); ++i) pr[i] = policy[batch[j].actions[i]] / ptotal;
+                    tree.expand_leaf(batch[j], pr.data(), value);
+                }
+            }
+            snprintf(line, sizeof(line), "move %d fen %s\n", m, tree.get_env().print().c_str()); text += line;
+            snprintf(line, sizeof(line), "root n %d w %.9g\n", tree.root->n, tree.root->w); text += line;
+            for (const Node* c : tree.root->children) {
+                snprintf(line, sizeof(line), "child %d n %d w %.9g p %.9g\n", c->action, c->n, c->w, c->p); text += line;
+            }
+            const int picked = m < npicks ? picks[m] : tree.pick(0.0f);
+            snprintf(line, sizeof(line), "pick %d\n", picked); text += line;
+            tree.push(picked);
+            float v;
+            if (tree.get_env().terminal(&v)) { snprintf(line, sizeof(line), "terminal %g\n", v); text += line; break; }
+        }
+        if ((int)text.size() + 1 > cap) return fail("output needs %zu bytes", text.size() + 1);
+        memcpy(out, text.c_str(), text.size() + 1);
+        return 0;
+    } catch (std::exception& e) {
+        return fail("%s", e.what());
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Self-play pool: Selfplay::inference_main (selfplay.cpp:58-213) with heap trees, several leaves per
+// tree and batch, compact observations in, legal priors out.
+struct ks_pool {
+    kh_engine* engine;
+    ks_pool_config cfg;
+    struct Game {
+        std::unique_ptr<MCTS> tree;
+        struct Step { kh_board board; std::vector<int> actions; std::vector<float> visits; float pov; };
+        std::vector<Step> trajectory;
+        std::vector<MCTS::Leaf> leaves;     // in flight
+    };
+    std::vector<Game> games;
+    std::mutex rec_mutex;
+    std::vector<ks_record> records;
+    std::atomic<int64_t> evals{ 0 }, batches{ 0 }, moves{ 0 }, finished{ 0 }, wwins{ 0 }, bwins{ 0 }, draws{ 0 }, nrecords{ 0 };
+    double seconds = 0.0;
+    std::string error;
+    std::mutex err_mutex;
+};
+
+namespace {
+
+void finish_game(ks_pool* p, ks_pool::Game& g, float value)
+{
+    const float draw_value = (p->cfg.draw_value_pct / 100.0f) * 2.0f - 1.0f;      // selfplay.cpp:71
+    std::vector<ks_record> out;
+    out.reserve(g.trajectory.size());
+    for (auto& t : g.trajectory) {
+        ks_record r;
+        memset(&r, 0, sizeof(r));
+        r.board = t.board;
+        r.value = value == 0.0f ? draw_value : t.pov * value;                       // selfplay.cpp:176-184
+        // keep the most visited KS_MAX_RECORD_ACTIONS moves (positions with more legal moves are rare)
+        std::vector<int> idx(t.actions.size());
+        for (size_t i = 0; i < idx.size(); ++i) idx[i] = (int)i;
+        if (idx.size() > KS_MAX_RECORD_ACTIONS) {
+            std::partial_sort(idx.begin(), idx.begin() + KS_MAX_RECORD_ACTIONS, idx.end(), [&](int a, int b) { return t.visits[a] > t.visits[b]; });
+            idx.resize(KS_MAX_RECORD_ACTIONS);
+            std::sort(idx.begin(), idx.end());
+        }
+        r.nact = (int32_t)idx.size();
+        for (size_t i = 0; i < idx.size(); ++i) { r.actions[i] = (int16_t)t.actions[idx[i]]; r.visits[i] = t.visits[idx[i]]; }
+        out.push_back(r);
+    }
+    {
+        std::lock_guard<std::mutex> lk(p->rec_mutex);
+        p->records.insert(p->records.end(), out.begin(), out.end());
+    }
+    p->nrecords += (int64_t)out.size();
+    p->finished += 1;
+    if (value > 0) p->wwins += 1; else if (value < 0) p->bwins += 1; else p->draws += 1;
+    g.trajectory.clear();
+    g.tree->reset();
+}
+
+// the tree has its visits: record the position, play a move (selfplay.cpp:131-189)
+void advance_game(ks_pool* p, ks_pool::Game& g)
+{
+    MCTS& tree = *g.tree;
+    Env& env = tree.get_env();
+    ks_pool::Game::Step st;
+    env.record(&st.board);
+    tree.snapshot_sparse(st.actions, st.visits);
+    st.pov = -env.turn();                                                           // selfplay.cpp:146
+    g.trajectory.push_back(std::move(st));
+    float alpha = p->cfg.alpha_final;
+    if (env.ply() < p->cfg.alpha_cutoff) alpha = std::pow(p->cfg.alpha_decay, (float)env.ply()) * p->cfg.alpha_initial;
+    tree.push(tree.pick(alpha));
+    p->moves += 1;
+    float value;
+    if (env.terminal(&value)) finish_game(p, g, value);
+}
+
+void worker(ks_pool* p, int g0, int g1, int64_t target_evals, double deadline_s, std::chrono::steady_clock::time_point t0)
+{
+    const int L = p->cfg.leaves_per_tree > 0 ? p->cfg.leaves_per_tree : 1;
+    std::vector<kh_board> boards;
+    std::vector<int32_t> offsets, actions;
+    std::vector<float> priors, values;
+    std::vector<std::pair<int, int>> owner;         // (game, leaf slot) of each batch row
+    try {
+        for (;;) {
+            if (p->evals.load() >= target_evals) break;
+            if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > deadline_s) break;
+            boards.clear(); offsets.assign(1, 0); actions.clear(); owner.clear();
+            for (int gi = g0; gi < g1; ++gi) {
+                ks_pool::Game& g = p->games[gi];
+                MCTS& tree = *g.tree;
+                g.leaves.clear();
+                for (;;) {
+                    const int inflight = (int)g.leaves.size();
+                    if (inflight == 0 && tree.n() >= p->cfg.nodes) { advance_game(p, g); continue; }
+                    if (inflight >= L || tree.n() + inflight >= p->cfg.nodes) break;
+                    g.leaves.emplace_back();
+                    bool blocked = false;
+                    if (tree.select_leaf(&g.leaves.back(), &blocked)) continue;
+                    g.leaves.pop_back();
+                    if (blocked) break;
+                }
+                for (size_t j = 0; j < g.leaves.size(); ++j) {
+                    boards.push_back(g.leaves[j].record);
+                    actions.insert(actions.end(), g.leaves[j].actions.begin(), g.leaves[j].actions.end());
+                    offsets.push_back((int32_t)actions.size());
+                    owner.emplace_back(gi, (int)j);
+                }
+            }
+            const int nb = (int)boards.size();
+            if (nb == 0) continue;
+            priors.resize(actions.size());
+            values.resize((size_t)nb);
+            const int rc = kh_encode_infer_legal(p->engine, boards.data(), nb, offsets.data(), actions.data(), priors.data(), values.data());
+            if (rc != KH_OK) throw std::runtime_error(std::string("kh_encode_infer_legal: ") + kh_last_error());
+            for (int j = 0; j < nb; ++j) {
+                ks_pool::Game& g = p->games[owner[j].first];
+                g.tree->expand_leaf(g.leaves[owner[j].second], priors.data() + offsets[j], values[j]);
+            }
+            p->evals += nb;
+            p->batches += 1;
+        }
+    } catch (std::exception& e) {
+        std::lock_guard<std::mutex> lk(p->err_mutex);
+        p->error = e.what();
+    }
+}
+
+}  // namespace
+
+int ks_pool_create(kh_engine* engine, const ks_pool_config* cfg, ks_pool** out)
+{
+    if (!engine || !cfg || !out) return fail("null argument");
+    if (cfg->games < 1 || cfg->threads < 1 || cfg->nodes < 2) return fail("games >= 1, threads >= 1, nodes >= 2 required");
+    ks_pool* p = new ks_pool();
+    p->engine = engine;
+    p->cfg = *cfg;
+    p->games.resize((size_t)cfg->games);
+    for (int i = 0; i < cfg->games; ++i) {
+        MCTSConfig mc;
+        mc.cpuct = cfg->cpuct > 0 ? cfg->cpuct : 1.0f;
+        mc.mcts_noise_weight = cfg->noise_weight;
+        mc.seed = cfg->seed * 2654435761u + (unsigned)i;
+        p->games[i].tree.reset(new MCTS(mc));
+    }
+    *out = p;
+    return 0;
+}
+
+int ks_pool_run(ks_pool* p, int64_t min_evals, double max_seconds, ks_pool_stats* stats)
+{
+    const auto t0 = std::chrono::steady_clock::now();
+    const int T = std::min(p->cfg.threads, p->cfg.games);
+    const int64_t target = p->evals.load() + min_evals;
+    std::vector<std::thread> th;
+    for (int t = 0; t < T; ++t) {
+        const int g0 = (int)((int64_t)p->cfg.games * t / T), g1 = (int)((int64_t)p->cfg.games * (t + 1) / T);
+        th.emplace_back(worker, p, g0, g1, target, max_seconds, t0);
+    }
+    for (auto& x : th) x.join();
+    p->seconds += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    // leaves still marked in flight belong to nobody now: none — every batch is expanded before a worker leaves
+    if (!p->error.empty()) return fail("%s", p->error.c_str());
+    if (stats) {
+        stats->evals = p->evals; stats->batches = p->batches; stats->moves = p->moves;
+        stats->games_finished = p->finished; stats->white_wins = p->wwins; stats->black_wins = p->bwins; stats->draws = p->draws;
+        stats->records = p->nrecords;
+        stats->seconds = p->seconds;
+        stats->evals_per_s = p->seconds > 0 ? (double)p->evals / p->seconds : 0.0;
+        stats->mean_batch = p->batches ? (double)p->evals / (double)p->batches : 0.0;
+    }
+    return 0;
+}
+
+int64_t ks_pool_drain_records(ks_pool* p, ks_record* out, int64_t cap)
+{
+    std::lock_guard<std::mutex> lk(p->rec_mutex);
+    const int64_t n = std::min<int64_t>(cap, (int64_t)p->records.size());
+    if (n > 0 && out) memcpy(out, p->records.data(), (size_t)n * sizeof(ks_record));
+    p->records.erase(p->records.begin(), p->records.begin() + n);
+    return n;
+}
+
+void ks_pool_destroy(ks_pool* p) { delete p; }
+
+}  // extern "C"

@@ -72,11 +72,33 @@ def gen_observe(tmp):
     return r
 
 
+def gen_search(tmp):
+    """Fixtures for the host search row: played games with the reference's terminal
+    verdict at every ply (Env::terminal, env.h:286-384) and the reference's own MCTS (kami/mcts.h)
+    run under a deterministic synthetic evaluator with the root noise switched off."""
+    path = os.path.join(tmp, "games.bin")
+    # 40 random games, up to 400 plies each, played on through the draw verdicts while a move exists
+    subprocess.check_call([REF, "games", "7", "40", "400", path])
+    rec = np.dtype([("ply", "<i4"), ("action", "<i4"), ("terminal", "<i4"), ("value", "<f4"), ("fen", "S104")])
+    r = np.fromfile(path, rec)
+    np.savez_compressed(os.path.join(OUT, "games.npz"), ply=r["ply"].astype(np.int16), action=r["action"].astype(np.int16),
+                        terminal=r["terminal"].astype(np.int8), value=r["value"], fen=r["fen"])
+    print("games fixture:", len(r), "plies,", int((r["ply"] == 0).sum()), "games,", int(r["terminal"].sum()), "terminal verdicts,",
+          "values", sorted(set(r["value"][r["terminal"] == 1].tolist())))
+    for nodes, nmoves, name in ((300, 12, "mcts_ref_300x12.txt"), (64, 120, "mcts_ref_64x120.txt")):
+        subprocess.check_call([REF, "mcts", str(nodes), str(nmoves), os.path.join(OUT, name)])
+        print("mcts fixture:", name, os.path.getsize(os.path.join(OUT, name)), "bytes")
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     if not os.path.exists(REF):
         sys.exit("oracle/_ref/kami_ref missing: run `make -C oracle` where /root/reference exists")
     with tempfile.TemporaryDirectory() as tmp:
+        if "--search-only" in sys.argv:
+            gen_search(tmp)
+            return
+        gen_search(tmp)
         recs = gen_observe(tmp)
         planes = recs["obs"].reshape(-1, 8, 8, 30)
         for name, F, C, R, B, seed, peaky, kind in NETS:

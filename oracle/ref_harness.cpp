@@ -11,8 +11,12 @@
 //   infer   <weights.bin> <input.f32> <B> <policy.f32> <value_flat.f32> <value_full.f32>
 //   observe <seed> <ngames> <maxply> <out.bin>
 //   bench   <F> <C> <R> <B> <iters> <threads>
+//   games   <seed> <ngames> <maxply> <out.bin>      random playouts: played action + terminal verdict per ply
+//   mcts    <nodes> <nmoves> <out.txt>              the reference's own MCTS (kami/mcts.h) under a
+//                                                   deterministic synthetic evaluator, noise off
 #include "kami/nn/nn.h"
 #include "kami/env.h"
+#include "kami/mcts.h"
 #include "kami/options.h"
 
 #include <torch/torch.h>
@@ -206,14 +210,98 @@ static int cmd_bench(int argc, char** argv)
     return 0;
 }
 
+// games record, little-endian: int32 ply; int32 action (played from this position, -1 = none);
+//   int32 terminal; float value; char fen[104]
+static int cmd_games(int argc, char** argv)
+{
+    if (argc < 6) return 1;
+    unsigned seed = (unsigned)atoi(argv[2]);
+    int ngames = atoi(argv[3]), maxply = atoi(argv[4]);
+    FILE* f = fopen(argv[5], "wb");
+    if (!f) return 2;
+    std::mt19937 rng(seed);
+    long nrec = 0;
+    for (int g = 0; g < ngames; ++g) {
+        Env e;
+        for (int ply = 0; ply <= maxply; ++ply) {
+            float value = 0.0f;
+            int32_t term = e.terminal(&value) ? 1 : 0;             // env.h:286-384
+            std::vector<int> acts = e.actions();
+            // like `observe`: keep playing through the draw verdicts while a legal move exists
+            int32_t action = (acts.empty() || ply == maxply) ? -1 : acts[rng() % acts.size()];
+            int32_t hdr[3] = { e.ply(), action, term };
+            char fen[104] = { 0 };
+            std::string s = e.print();
+            strncpy(fen, s.c_str(), sizeof(fen) - 1);
+            fwrite(hdr, 4, 3, f); fwrite(&value, 4, 1, f); fwrite(fen, 1, 104, f);
+            ++nrec;
+            if (action < 0) break;
+            e.push(action);
+        }
+    }
+    fclose(f);
+    printf("%ld records\n", nrec);
+    return 0;
+}
+
+// Synthetic evaluator shared with tests/test_search.py: FNV-1a of the FEN, splitmix64 per action.
+static uint64_t fnv1a(const std::string& s)
+{
+    uint64_t h = 1469598103934665603ull;
+    for (unsigned char c : s) { h ^= c; h *= 1099511628211ull; }
+    return h;
+}
+static uint64_t splitmix(uint64_t x)
+{
+    x += 0x9e3779b97f4a7c15ull;
+    x = (x ^ (x >> 30)) * 0xbf58476d1ce4e5b9ull;
+    x = (x ^ (x >> 27)) * 0x94d049bb133111ebull;
+    return x ^ (x >> 31);
+}
+
+static int cmd_mcts(int argc, char** argv)
+{
+    if (argc < 5) return 1;
+    int nodes = atoi(argv[2]), nmoves = atoi(argv[3]);
+    FILE* f = fopen(argv[4], "w");
+    if (!f) return 2;
+    options::setFloat("mcts_noise_weight", 0.0f);                // mcts.h:91: priors = policy / ptotal exactly
+    MCTS tree;                                                     // mcts.h:66
+    std::vector<float> obs(OBSIZE), policy(PSIZE);
+    for (int m = 0; m < nmoves; ++m) {
+        while (tree.n() < nodes) {
+            if (!tree.select(obs.data())) continue;                // mcts.h:183-259 (terminal leaves backprop inside)
+            const uint64_t h = fnv1a(tree.get_env().print());
+            double sum = 0.0;
+            for (int a = 0; a < PSIZE; ++a) { policy[a] = (float)(splitmix(h + (uint64_t)a) % 16777213ull + 1); sum += policy[a]; }
+            for (int a = 0; a < PSIZE; ++a) policy[a] = (float)(policy[a] / sum);
+            const float value = ((float)(splitmix(h ^ 0x7777) % 2001) - 1000.0f) / 1000.0f;
+            tree.expand(policy.data(), value);                     // mcts.h:261-327
+        }
+        fprintf(f, "move %d fen %s\n", m, tree.get_env().print().c_str());
+        fprintf(f, "root n %d w %.9g\n", tree.root->n, tree.root->w);
+        for (Node* c : tree.root->children)
+            fprintf(f, "child %d n %d w %.9g p %.9g\n", c->action, c->n, c->w, c->p);
+        int picked = tree.pick(0.0f);                              // mcts.h:139-181
+        fprintf(f, "pick %d\n", picked);
+        tree.push(picked);                                         // mcts.h:114-137
+        float v;
+        if (tree.get_env().terminal(&v)) { fprintf(f, "terminal %g\n", v); break; }
+    }
+    fclose(f);
+    return 0;
+}
+
 int main(int argc, char** argv)
 {
-    if (argc < 2) { fprintf(stderr, "usage: kami_ref infer|observe|bench ...\n"); return 1; }
+    if (argc < 2) { fprintf(stderr, "usage: kami_ref infer|observe|bench|games|mcts ...\n"); return 1; }
     std::string c = argv[1];
     try {
         if (c == "infer") return cmd_infer(argc, argv);
         if (c == "observe") return cmd_observe(argc, argv);
         if (c == "bench") return cmd_bench(argc, argv);
+        if (c == "games") return cmd_games(argc, argv);
+        if (c == "mcts") return cmd_mcts(argc, argv);
     } catch (std::exception& e) {
         fprintf(stderr, "kami_ref: %s\n", e.what());
         return 3;

@@ -27,6 +27,20 @@ def test_header_symbols_all_exported():
     assert set(names) == set(L.SYMBOLS), "ctypes table and header disagree"
 
 
+def test_search_header_symbols_all_exported():
+    """include/kami_search.h (host search row) against libkamisearch.so and its ctypes table."""
+    from kami_amd import search as S
+    text = open(os.path.join(ROOT, "include", "kami_search.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    names = sorted(set(re.findall(r"\b(ks_[a-z0-9_]+)\s*\(", text)))
+    lib = S.load()
+    assert len(names) >= 15
+    for n in names:
+        assert hasattr(lib, n), f"{n} declared in kami_search.h but not exported"
+    assert set(names) == set(S.SYMBOLS), "ctypes table and header disagree"
+    assert C.sizeof(S.PoolConfig) == 64 and C.sizeof(S.Record) == 80 + 8 + 96 * 2 + 96 * 4
+
+
 def test_struct_layouts():
     assert C.sizeof(L.Config) == 64
     assert L.BOARD_DTYPE.itemsize == 80

@@ -462,3 +462,51 @@ def test_encode_full_size_properties():
     assert np.array_equal(planes[:4096, :, 18:].sum((1, 2)).astype(int), npieces)               # one plane bit per piece
     assert set(np.unique(planes[:, 0, 14:18])) <= {0.0, 1.0, 2.0, 4.0, 8.0}                     # raw castle bits (Q2)
     assert np.array_equal(planes[:, 0, 0], (boards["ply"] & 1).astype(np.float32))
+
+
+# ---------------------------------------------------------------------------------------------
+# host search row: the self-play pool drives the engine with compact records
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("leaves", [1, 4])
+def test_selfplay_pool_feeds_engine(leaves):
+    from kami_amd import search as S
+    F, C, R = 30, 64, 2
+    nn = NN(8, 8, F, 4672, filters=C, residuals=R, dtype="bf16", value_mode=L.KH_VALUE_PER_SAMPLE0)
+    nn.load_weights(W.random_weights(F, C, R, seed=5, peaky=5.0), 1)
+    pool = S.Pool(nn, games=96, threads=3, nodes=24, leaves_per_tree=leaves, seed=3)
+    st = pool.run(min_evals=40000, max_seconds=60.0)
+    assert st.evals >= 40000 and st.batches > 0
+    assert st.mean_batch >= 32                         # a worker's batch is (at least) one leaf of each of its 32 trees
+    assert st.moves > st.evals // 30                   # >= one move per `nodes` visits (terminal visits are free)
+    recs = pool.drain()
+    assert st.records == len(recs)
+    assert st.games_finished == st.white_wins + st.black_wins + st.draws
+    for r in recs[:200]:
+        v = np.array(r.visits[:r.nact])
+        assert 0 < r.nact <= S.MAX_RECORD_ACTIONS and abs(v.sum() - 1.0) < 1e-3 and (v >= 0).all()
+        assert r.value in (-1.0, 0.0, 1.0)
+    # the records' boards encode like any other record (device encoder)
+    b = np.frombuffer(b"".join(bytes(r.board) for r in recs[:64]), dtype=L.BOARD_DTYPE)
+    planes = nn.encode(b)
+    assert planes.shape == (len(b), 8, 8, 30) and np.isin(planes, [0, 1, 2, 4, 8]).all()
+
+
+@pytest.mark.gpu
+def test_pool_priors_are_the_reference_expansion():
+    """One position: the priors the pool's evaluator call returns (kh_encode_infer_legal on Env::record +
+    Env::actions) equal policy[a] / sum over legal a of the full policy row (mcts.h:273-276)."""
+    from kami_amd import search as S
+    F, C, R = 30, 32, 1
+    nn = NN(8, 8, F, 4672, filters=C, residuals=R, dtype="f32")
+    nn.load_weights(W.random_weights(F, C, R, seed=9, peaky=10.0), 1)
+    env = S.Env()
+    for a in (877, 657, 949):              # a few plies into a game (actions from the mcts fixture)
+        env.push(a)
+    rec = env.record()
+    acts = np.array(env.actions(), np.int32)
+    pri, val = nn.infer_legal(rec, np.array([0, len(acts)], np.int32), acts)
+    p, v = nn.encode_infer(rec)
+    want = p[0, acts] / p[0, acts].sum()
+    np.testing.assert_allclose(pri, want, rtol=1e-5)
+    assert abs(pri.sum() - 1.0) < 1e-5

@@ -1,0 +1,17 @@
+"""Leaf evaluations per second through the WHOLE host path: search trees -> compact records ->
+kh_encode_infer_legal -> priors -> expansion (tools/host_path_bench.py times the engine calls alone)."""
+import sys, os, time
+sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
+from kami_amd import NN, weights as W, search as S, _lib as L
+F, C, R = 30, 64, 6
+nn = NN(8, 8, F, 4672, filters=C, residuals=R, dtype="bf16", value_mode=L.KH_VALUE_PER_SAMPLE0)
+nn.load_weights(W.random_weights(F, C, R, seed=1, peaky=5.0), 1)
+for games, threads, leaves, nodes in ((512, 1, 1, 64), (2048, 4, 1, 64), (2048, 8, 1, 64), (4096, 8, 1, 64), (1024, 8, 4, 64), (4096, 16, 1, 64)):
+    pool = S.Pool(nn, games=games, threads=threads, nodes=nodes, leaves_per_tree=leaves, seed=1)
+    pool.run(min_evals=20000, max_seconds=10.0)          # warm-up
+    s0 = pool.run(min_evals=0, max_seconds=0.0)
+    st = pool.run(min_evals=400000, max_seconds=8.0)
+    de, dt = st.evals - s0.evals, st.seconds - s0.seconds
+    print(f"games {games:5d} threads {threads:2d} leaves/tree {leaves}: {de / dt:12,.0f} leaf-evals/s  mean batch {st.mean_batch:7.1f}  "
+          f"moves {st.moves}  games finished {st.games_finished} (W {st.white_wins} / B {st.black_wins} / D {st.draws})", flush=True)
+    del pool
