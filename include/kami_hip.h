@@ -104,6 +104,26 @@ void kh_destroy(kh_engine* e);
  * parameter set + generation.  In-flight kh_infer calls finish on the old set. */
 int  kh_load_weights(kh_engine* e, const float* blob, size_t nfloats, int generation);
 
+/* NN::train nn.cpp:224-377: `epochs` passes of plain SGD (batch `batch`, learning rate `lr`) over
+ * `trajectories` samples, in the reference's order (one default_random_engine shuffled per epoch;
+ * the last, short batch of an epoch is padded with the previous batch's rows like the reference's
+ * stack buffers), network in training mode (BatchNorm on batch statistics, running statistics
+ * updated), loss = -sum(obs_p * log(p + 0.001)) + mean((v - obs_v)^2) (nn.cpp:93-105).  The trained
+ * parameters become the engine's weights with generation + 1.  fp32 arithmetic whatever cfg.dtype.
+ *   inputs [n][8][8][F], obs_p [n][4672], obs_v [n]; first_loss / last_loss: average loss of the first
+ * and last epoch (the reference prints them), nullable. */
+typedef struct kh_train_config {
+    float   lr;             /* "training_mlr" / 1000  (nn.cpp:236)  */
+    int32_t epochs;         /* "training_epochs"       (nn.cpp:237)  */
+    int32_t batch;          /* "training_batchsize"    (nn.cpp:238)  */
+    int32_t reserved[5];
+} kh_train_config;
+int  kh_train(kh_engine* e, const float* inputs, const float* obs_p, const float* obs_v, int trajectories,
+              const kh_train_config* cfg, float* first_loss, float* last_loss);
+
+/* The engine's current fp32 parameter set in blob order (what NN::write would serialise, nn.cpp:189-202). */
+int  kh_get_weights(kh_engine* e, float* blob, size_t nfloats);
+
 /* NN::get_generation nn.h:53-59. */
 int  kh_generation(kh_engine* e);
 

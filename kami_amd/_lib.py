@@ -31,11 +31,17 @@ assert BOARD_DTYPE.itemsize == 80
 
 # every symbol include/kami_hip.h declares: name -> (restype, argtypes)
 _P = C.c_void_p
+class TrainConfig(C.Structure):
+    _fields_ = [("lr", C.c_float), ("epochs", C.c_int32), ("batch", C.c_int32), ("reserved", C.c_int32 * 5)]
+
+
 SYMBOLS = {
     "kh_weight_count": (C.c_size_t, [C.c_int, C.c_int, C.c_int]),
     "kh_create": (C.c_int, [C.POINTER(Config), C.POINTER(_P)]),
     "kh_destroy": (None, [_P]),
     "kh_load_weights": (C.c_int, [_P, _P, C.c_size_t, C.c_int]),
+    "kh_train": (C.c_int, [_P, _P, _P, _P, C.c_int, C.POINTER(TrainConfig), C.POINTER(C.c_float), C.POINTER(C.c_float)]),
+    "kh_get_weights": (C.c_int, [_P, _P, C.c_size_t]),
     "kh_generation": (C.c_int, [_P]),
     "kh_clone": (C.c_int, [_P, C.POINTER(_P)]),
     "kh_infer": (C.c_int, [_P, _P, C.c_int, _P, _P]),

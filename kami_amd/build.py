@@ -21,7 +21,7 @@ CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(CSRC, "build")
 LIB = os.path.join(HERE, "libkamihip.so")
 ARCH = "gfx950"
-SOURCES = ["kh_api.hip", "encode.hip", "forward_simple.hip", "tower_mfma.hip", "layers_mfma.hip"]
+SOURCES = ["kh_api.hip", "encode.hip", "forward_simple.hip", "tower_mfma.hip", "layers_mfma.hip", "train.hip"]
 # MFMA results in arch VGPRs: the epilogues read them with VALU ops and would otherwise pay a
 # v_accvgpr_read per value (the kernel runs one wave per SIMD, registers are not scarce).
 EXTRA_FLAGS = {"tower_mfma.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"]}

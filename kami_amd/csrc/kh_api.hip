@@ -15,6 +15,8 @@
 #include <cstring>
 #include <memory>
 #include <mutex>
+#include <random>
+#include <algorithm>
 #include <string>
 #include <vector>
 
@@ -709,6 +711,84 @@ int kh_load_weights(kh_engine* e, const float* blob, size_t nfloats, int generat
     }
     std::lock_guard<std::mutex> lk(e->wmu);
     e->weights = W;                  // calls in flight keep their own reference
+    return KH_OK;
+}
+
+int kh_train(kh_engine* e, const float* inputs, const float* obs_p, const float* obs_v, int trajectories,
+             const kh_train_config* cfg, float* first_loss, float* last_loss)
+{
+    if (!e || !inputs || !obs_p || !obs_v || !cfg) return fail(KH_ERR_INVALID, "null argument");
+    if (trajectories < 1 || cfg->batch < 2 || cfg->epochs < 1) return fail(KH_ERR_INVALID, "trajectories >= 1, batch >= 2, epochs >= 1 required");
+    auto W = current_weights(e);
+    if (!W) return fail(KH_ERR_NO_WEIGHTS, "kh_train before kh_load_weights");
+    int rc = set_device(e);
+    if (rc) return rc;
+    const int F = e->cfg.features, C = e->cfg.filters, R = e->cfg.residuals, B = cfg->batch;
+    std::unique_ptr<kh::TrainNet, void (*)(kh::TrainNet*)> net(kh::train_layout_new(F, C, R), kh::train_layout_free);
+    const size_t nfl = W->blob.size();
+    DevMem params, grads, work, dx, dp, dv, dloss;
+    if ((rc = params.ensure(nfl * 4)) || (rc = grads.ensure(nfl * 4)) || (rc = work.ensure(kh::train_workspace_floats(F, C, R, B) * 4)) ||
+        (rc = dx.ensure((size_t)B * 64 * F * 4)) || (rc = dp.ensure((size_t)B * KH_PSIZE * 4)) || (rc = dv.ensure((size_t)B * 4)) ||
+        (rc = dloss.ensure((size_t)B * 2 * 4)))
+        return rc;
+    hipStream_t st;
+    HIPCHK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+    struct StreamGuard { hipStream_t s; ~StreamGuard() { (void)hipStreamDestroy(s); } } guard{ st };
+    HIPCHK(hipMemcpyAsync(params.p, W->blob.data(), nfl * 4, hipMemcpyHostToDevice, st));
+
+    // nn.cpp:245-262: one engine for the whole call, one shuffle per epoch; staging rows persist
+    std::vector<int> picker((size_t)trajectories);
+    for (int i = 0; i < trajectories; ++i) picker[i] = i;
+    auto rng = std::default_random_engine{};
+    const size_t in_row = (size_t)64 * F;
+    std::vector<float> next_input((size_t)B * in_row, 0.0f), next_policy((size_t)B * KH_PSIZE, 0.0f), next_value((size_t)B, 0.0f);
+    std::vector<float> loss_rows((size_t)B * 2);
+    float firstloss = 0.0f, lastloss = 0.0f;
+    const kh::StepBuffers sb{ params.as<float>(), grads.as<float>(), work.as<float>() };
+    for (int epoch = 0; epoch < cfg->epochs; ++epoch) {
+        std::shuffle(picker.begin(), picker.end(), rng);
+        float avgloss = 0.0f;
+        int nbatches = 0;
+        for (int base = 0; base <= trajectories - 1;) {
+            int i = 0;
+            for (; i < B && i + base <= trajectories - 1; ++i) {
+                const size_t src = (size_t)picker[base + i];
+                memcpy(&next_input[(size_t)i * in_row], inputs + src * in_row, in_row * 4);
+                memcpy(&next_policy[(size_t)i * KH_PSIZE], obs_p + src * KH_PSIZE, (size_t)KH_PSIZE * 4);
+                next_value[i] = obs_v[src];
+            }
+            base += i;
+            HIPCHK(hipMemcpyAsync(dx.p, next_input.data(), next_input.size() * 4, hipMemcpyHostToDevice, st));
+            HIPCHK(hipMemcpyAsync(dp.p, next_policy.data(), next_policy.size() * 4, hipMemcpyHostToDevice, st));
+            HIPCHK(hipMemcpyAsync(dv.p, next_value.data(), next_value.size() * 4, hipMemcpyHostToDevice, st));
+            HIPCHK(kh::train_step(*net, sb, dx.as<float>(), dp.as<float>(), dv.as<float>(), B, cfg->lr, dloss.as<float>(), st));
+            HIPCHK(hipMemcpyAsync(loss_rows.data(), dloss.p, loss_rows.size() * 4, hipMemcpyDeviceToHost, st));
+            HIPCHK(hipStreamSynchronize(st));
+            float lp = 0.0f, lv = 0.0f;
+            for (int b = 0; b < B; ++b) { lp += loss_rows[b]; lv += loss_rows[B + b]; }
+            const float loss = lp + lv / (float)(B * KH_VALUE_WIDTH);
+            if (loss != loss) return fail(KH_ERR_NAN_POLICY, "training loss is NaN (epoch %d, batch %d)", epoch, nbatches);
+            avgloss += loss;
+            ++nbatches;
+        }
+        avgloss /= (float)nbatches;
+        if (!epoch) firstloss = avgloss;
+        lastloss = avgloss;
+    }
+    std::vector<float> blob(nfl);
+    HIPCHK(hipMemcpy(blob.data(), params.p, nfl * 4, hipMemcpyDeviceToHost));
+    if (first_loss) *first_loss = firstloss;
+    if (last_loss) *last_loss = lastloss;
+    return kh_load_weights(e, blob.data(), nfl, W->generation + 1);         // nn.cpp:371 ++generation
+}
+
+int kh_get_weights(kh_engine* e, float* blob, size_t nfloats)
+{
+    if (!e || !blob) return fail(KH_ERR_INVALID, "null argument");
+    auto W = current_weights(e);
+    if (!W) return fail(KH_ERR_NO_WEIGHTS, "no weights loaded");
+    if (nfloats != W->blob.size()) return fail(KH_ERR_INVALID, "blob has %zu floats, caller asked for %zu", W->blob.size(), nfloats);
+    memcpy(blob, W->blob.data(), nfloats * sizeof(float));
     return KH_OK;
 }
 

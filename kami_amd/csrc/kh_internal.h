@@ -83,4 +83,14 @@ struct LayersArgs {
 size_t layers_lds_bytes(int Ci);
 hipError_t launch_layers(int dtype, const LayersArgs& L, hipStream_t s);
 
+// ---- train.hip ------------------------------------------------------------------------------
+// NN::train (nn.cpp:224-377) as fp32 device kernels: one SGD step per call on a device parameter blob.
+struct TrainNet;
+struct StepBuffers { float* params; float* grads; float* work; };
+TrainNet* train_layout_new(int F, int C, int R);
+void train_layout_free(TrainNet* n);
+size_t train_workspace_floats(int F, int C, int R, int B);
+hipError_t train_step(const TrainNet& n, const StepBuffers& sb, const float* x_in, const float* obsp, const float* obsv,
+                      int B, float lr, float* loss_rows, hipStream_t s);
+
 }  // namespace kh

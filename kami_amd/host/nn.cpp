@@ -135,10 +135,25 @@ void NN::infer(float* input, int batch, float* policy, float* value)
     if (rc) raise(rc);
 }
 
-void NN::train(int, float*, float*, float*, bool)
+void NN::train(int trajectories, float* inputs, float* obs_p, float* obs_v, bool)
 {
-    throw std::runtime_error("kami::NN::train is not implemented by the MI355X leaf-evaluation engine "
-                             "(training is outside the accelerated path)");
+    // nn.cpp:236-238: the three option keys the reference reads
+    kh_train_config cfg;
+    std::memset(&cfg, 0, sizeof cfg);
+    cfg.lr = (float)options::getInt("training_mlr", 5) / 1000.0f;
+    cfg.epochs = options::getInt("training_epochs", 8);
+    cfg.batch = options::getInt("training_batchsize", 8);
+    float first = 0.0f, last = 0.0f;
+    int rc = kh_train(eng, inputs, obs_p, obs_v, trajectories, &cfg, &first, &last);
+    if (rc) raise(rc);
+    std::vector<float> blob(kh_weight_count(features, filters, residuals));
+    if ((rc = kh_get_weights(eng, blob.data(), blob.size()))) raise(rc);
+    {
+        std::lock_guard<std::mutex> lk(g_store_mu);
+        g_store[this] = blob;
+    }
+    std::cout << "Generated model " << get_generation() << ", average loss " << first << " to " << last << " over "
+              << cfg.epochs << " epochs\n";                      // nn.cpp:372
 }
 
 void NN::write(std::string path)

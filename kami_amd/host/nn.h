@@ -10,8 +10,8 @@
 //     (the reference serialises with a shared_mutex, nn.cpp:166,206);
 //   - "filters" / "residuals" come from kami::options like the reference's module (nn.cpp:42-43).
 // Differences, on purpose: the engine only exists on the GPU (isCUDA() is always true, there is
-// no force_cpu path: construction throws without an MI355X); train() is not part of this path
-// yet and throws; read()/write() use the engine's own blob format (kami_amd/weights.py).
+// no force_cpu path: construction throws without an MI355X); train() runs the reference's SGD loop on
+// the device in fp32 (kh_train); read()/write() use the engine's own blob format (kami_amd/weights.py).
 #pragma once
 
 #include <string>

@@ -55,6 +55,29 @@ class NN:
     def get_generation(self) -> int:
         return self._lib.kh_generation(self._h)
 
+    def train(self, inputs: np.ndarray, obs_p: np.ndarray, obs_v: np.ndarray, *, mlr: int = 5, epochs: int = 8,
+              batchsize: int = 8):
+        """NN::train (nn.cpp:224-377) on the device; option names and defaults of nn.cpp:236-238.
+        Returns (average loss of the first epoch, of the last epoch); the generation goes up by one."""
+        x = np.ascontiguousarray(inputs, dtype=np.float32)
+        p = np.ascontiguousarray(obs_p, dtype=np.float32)
+        v = np.ascontiguousarray(obs_v, dtype=np.float32)
+        n = x.shape[0]
+        assert p.shape == (n, PSIZE) and v.shape == (n,)
+        cfg = L.TrainConfig(mlr / 1000.0, epochs, batchsize)
+        first, last = C.c_float(), C.c_float()
+        _chk(self._lib.kh_train(self._h, x.ctypes.data_as(C.c_void_p), p.ctypes.data_as(C.c_void_p),
+                                v.ctypes.data_as(C.c_void_p), n, C.byref(cfg), C.byref(first), C.byref(last)))
+        self._blob = self.get_weights()
+        return first.value, last.value
+
+    def get_weights(self) -> np.ndarray:
+        """The engine's current fp32 parameters in blob order (kh_get_weights)."""
+        n = self._lib.kh_weight_count(self.cfg.features, self.cfg.filters, self.cfg.residuals)
+        out = np.empty(n, np.float32)
+        _chk(self._lib.kh_get_weights(self._h, _ptr(out), n))
+        return out
+
     def isCUDA(self) -> bool:            # nn.h:62 — true: the engine only exists on the GPU
         return True
 

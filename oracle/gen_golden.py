@@ -90,6 +90,40 @@ def gen_search(tmp):
         print("mcts fixture:", name, os.path.getsize(os.path.join(OUT, name)), "bytes")
 
 
+def gen_train(tmp):
+    """NN::train (nn.cpp:224-377) on the reference: trained parameters after a few SGD epochs.
+    One batch per epoch (n == training_batchsize) on purpose: on the CPU device the reference's batch
+    tensors of an epoch all alias ONE stack buffer (`from_blob(next_input).to(kCPU)` does not copy,
+    nn.cpp:296-312), so with several batches per epoch every step of the epoch would train on the last
+    batch built; on its CUDA path `.to(device)` copies and the batches are distinct.  kh_train follows the
+    CUDA path, and single-batch epochs are where the two coincide."""
+    for name, F, C, R, n, tbatch, epochs, mlr, seed in (("train_f30_c16_r1", 30, 16, 1, 8, 8, 4, 5, 11),
+                                                        ("train_f30_c8_r2", 30, 8, 2, 6, 6, 5, 20, 12)):
+        rng = np.random.default_rng(seed)
+        blob = W.random_weights(F, C, R, seed=seed, peaky=3.0)
+        x = (rng.integers(0, 256, (n, 8, 8, F)).astype(np.float32) / 256.0)
+        # visit distributions over ~30 random "legal" actions per sample, targets in {-1, 0, 1}
+        idx = np.stack([rng.choice(4672, 32, replace=False) for _ in range(n)]).astype(np.int16)
+        val = rng.random((n, 32)).astype(np.float32)
+        val /= val.sum(1, keepdims=True)
+        obs_p = np.zeros((n, 4672), np.float32)
+        for i in range(n):
+            obs_p[i, idx[i]] = val[i]
+        obs_v = rng.choice(np.array([-1.0, 0.0, 1.0], np.float32), n)
+        wpath = os.path.join(tmp, "w.bin")
+        W.save(wpath, blob, F, C, R, 3)
+        paths = [os.path.join(tmp, f) for f in ("x.f32", "p.f32", "v.f32", "out.f32")]
+        x.tofile(paths[0]); obs_p.tofile(paths[1]); obs_v.tofile(paths[2])
+        subprocess.check_call([REF, "train", wpath, str(n), paths[0], paths[1], paths[2], str(mlr), str(epochs), str(tbatch), paths[3]],
+                              stdout=subprocess.DEVNULL)
+        trained = np.fromfile(paths[3], "<f4")
+        assert trained.size == blob.size and np.isfinite(trained).all()
+        np.savez_compressed(os.path.join(OUT, name + ".npz"), features=F, filters=C, residuals=R, blob=blob, trained=trained,
+                            x_u8=(x * 256).astype(np.uint8), obs_idx=idx, obs_val=val, obs_v=obs_v,
+                            tbatch=tbatch, epochs=epochs, mlr=mlr)
+        print("train fixture:", name, "max |delta w|", float(np.abs(trained - blob).max()))
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     if not os.path.exists(REF):
@@ -98,7 +132,11 @@ def main():
         if "--search-only" in sys.argv:
             gen_search(tmp)
             return
+        if "--train-only" in sys.argv:
+            gen_train(tmp)
+            return
         gen_search(tmp)
+        gen_train(tmp)
         recs = gen_observe(tmp)
         planes = recs["obs"].reshape(-1, 8, 8, 30)
         for name, F, C, R, B, seed, peaky, kind in NETS:

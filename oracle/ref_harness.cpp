@@ -12,6 +12,9 @@
 //   observe <seed> <ngames> <maxply> <out.bin>
 //   bench   <F> <C> <R> <B> <iters> <threads>
 //   games   <seed> <ngames> <maxply> <out.bin>      random playouts: played action + terminal verdict per ply
+//   train   <weights.bin> <n> <inputs.f32> <obs_p.f32> <obs_v.f32> <mlr> <epochs> <tbatch> <out_blob.f32>
+//                                                   NN::train (nn.cpp:224-377) from the given weights; dumps the
+//                                                   trained parameters + BatchNorm statistics in blob order
 //   mcts    <nodes> <nmoves> <out.txt>              the reference's own MCTS (kami/mcts.h) under a
 //                                                   deterministic synthetic evaluator, noise off
 #include "kami/nn/nn.h"
@@ -210,6 +213,54 @@ static int cmd_bench(int argc, char** argv)
     return 0;
 }
 
+static int cmd_train(int argc, char** argv)
+{
+    if (argc < 11) return 1;
+    Blob b = read_blob(argv[2]);
+    const int n = atoi(argv[3]);
+    options::setInt("filters", b.C);
+    options::setInt("residuals", b.R);
+    options::setInt("training_mlr", atoi(argv[7]));                // nn.cpp:236 (lr = mlr / 1000)
+    options::setInt("training_epochs", atoi(argv[8]));             // nn.cpp:237
+    options::setInt("training_batchsize", atoi(argv[9]));          // nn.cpp:238
+    auto mod = std::make_shared<NNModule>(8, 8, b.F, PSIZE);
+    fill_module(*mod, b);
+    std::string tmp = std::string(argv[10]) + ".model.pt";
+    {
+        torch::serialize::OutputArchive a;
+        mod->save(a);
+        a.write("generation", torch::IValue(b.gen));
+        a.save_to(tmp);
+    }
+    NN net(8, 8, b.F, PSIZE, /*force_cpu=*/true);
+    net.read(tmp);
+    std::vector<char> in = slurp(argv[4]), op = slurp(argv[5]), ov = slurp(argv[6]);
+    if (in.size() != (size_t)n * 64 * b.F * 4 || op.size() != (size_t)n * PSIZE * 4 || ov.size() != (size_t)n * 4) {
+        fprintf(stderr, "training data size mismatch\n"); return 2;
+    }
+    net.train(n, (float*)in.data(), (float*)op.data(), (float*)ov.data());   // nn.cpp:224-377
+    net.write(tmp);                                                // nn.cpp:189-202
+    auto out = std::make_shared<NNModule>(8, 8, b.F, PSIZE);
+    {
+        torch::serialize::InputArchive a;
+        a.load_from(tmp);
+        out->load(a);
+    }
+    remove(tmp.c_str());
+    auto params = out->named_parameters(true);
+    auto bufs = out->named_buffers(true);
+    std::vector<float> blob;
+    for (auto& name : canonical_names(b.R)) {
+        torch::Tensor t = params.contains(name) ? params[name] : bufs[name];
+        t = t.contiguous().to(torch::kFloat32);
+        const float* p = t.data_ptr<float>();
+        blob.insert(blob.end(), p, p + t.numel());
+    }
+    dump(argv[10], blob.data(), blob.size() * 4);
+    printf("generation %d floats %zu\n", net.get_generation(), blob.size());
+    return 0;
+}
+
 // games record, little-endian: int32 ply; int32 action (played from this position, -1 = none);
 //   int32 terminal; float value; char fen[104]
 static int cmd_games(int argc, char** argv)
@@ -302,6 +353,7 @@ int main(int argc, char** argv)
         if (c == "bench") return cmd_bench(argc, argv);
         if (c == "games") return cmd_games(argc, argv);
         if (c == "mcts") return cmd_mcts(argc, argv);
+        if (c == "train") return cmd_train(argc, argv);
     } catch (std::exception& e) {
         fprintf(stderr, "kami_ref: %s\n", e.what());
         return 3;

@@ -1,0 +1,96 @@
+"""NN::train (nn.cpp:224-377) on the device against the reference's own training runs.
+
+Fixtures (oracle/gen_golden.py, `kami_ref train`): initial blob, samples, the reference's option values and
+the parameters + BatchNorm statistics the unmodified reference holds after NN::train (libtorch CPU, fp32)."""
+import os
+
+import numpy as np
+import pytest
+
+from kami_amd import NN, weights as W, _lib as L
+
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def load(name):
+    d = np.load(os.path.join(GOLD, name + ".npz"))
+    n = d["x_u8"].shape[0]
+    obs_p = np.zeros((n, 4672), np.float32)
+    for i in range(n):
+        obs_p[i, d["obs_idx"][i]] = d["obs_val"][i]
+    return d, d["x_u8"].astype(np.float32) / 256.0, obs_p, d["obs_v"].astype(np.float32)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["train_f30_c16_r1", "train_f30_c8_r2"])
+def test_train_matches_reference(name):
+    d, x, obs_p, obs_v = load(name)
+    F, C, R = int(d["features"]), int(d["filters"]), int(d["residuals"])
+    nn = NN(8, 8, F, 4672, filters=C, residuals=R, dtype="f32")
+    nn.load_weights(d["blob"], 3)
+    first, last = nn.train(x, obs_p, obs_v, mlr=int(d["mlr"]), epochs=int(d["epochs"]), batchsize=int(d["tbatch"]))
+    assert nn.get_generation() == 4                                  # nn.cpp:371
+    assert np.isfinite([first, last]).all() and last < first         # it learns
+    got, want = nn.get_weights(), d["trained"]
+    # every tensor of the blob, parameters and running statistics alike.  fp32 both sides, different
+    # summation orders over a handful of SGD steps: agreement to ~1e-4 of each tensor's scale.
+    off = 0
+    for tname, shape in W.tensor_specs(F, C, R):
+        k = int(np.prod(shape))
+        a, b = got[off:off + k], want[off:off + k]
+        scale = max(1e-3, float(np.abs(b).max()))
+        assert np.abs(a - b).max() <= 2e-4 * scale + 2e-6, (tname, float(np.abs(a - b).max()), scale)
+        moved = float(np.abs(b - d["blob"][off:off + k]).max())
+        if tname.endswith("running_var") or tname.endswith("weight") and "conv" in tname:
+            assert moved > 0                                         # the step really reached this tensor
+        off += k
+    assert off == got.size
+    # the trained engine evaluates with the new weights: same outputs as a fresh engine loaded with them
+    fresh = NN(8, 8, F, 4672, filters=C, residuals=R, dtype="f32")
+    fresh.load_weights(got, 4)
+    p1, v1 = nn.infer(x[:5])
+    p2, v2 = fresh.infer(x[:5])
+    assert np.array_equal(p1, p2) and np.array_equal(v1, v2)
+
+
+@pytest.mark.gpu
+def test_train_updates_serving_engine_of_any_dtype():
+    """kh_train runs in fp32 whatever the engine's serving precision; the bf16 engine serves the trained net."""
+    d, x, obs_p, obs_v = load("train_f30_c16_r1")
+    F, C, R = int(d["features"]), int(d["filters"]), int(d["residuals"])
+    a = NN(8, 8, F, 4672, filters=C, residuals=R, dtype="bf16")
+    a.load_weights(d["blob"], 0)
+    p0, _ = a.infer(x[:4])
+    a.train(x, obs_p, obs_v, mlr=int(d["mlr"]), epochs=int(d["epochs"]), batchsize=int(d["tbatch"]))
+    assert a.get_generation() == 1
+    np.testing.assert_allclose(a.get_weights(), d["trained"], atol=5e-4, rtol=5e-4)
+    p1, _ = a.infer(x[:4])
+    assert not np.array_equal(p0, p1)
+    with pytest.raises(Exception):
+        a.train(x, obs_p, obs_v, batchsize=1)
+
+
+@pytest.mark.gpu
+def test_train_epochs_compose_and_batches_are_distinct():
+    """(a) two epochs in one call == two one-epoch calls (single batch per epoch: no shuffle dependence);
+    (b) with two batches per epoch both batches are used (the CUDA-path behaviour of nn.cpp:296-312, not
+    the CPU path's aliasing of every batch tensor to the last one built): training on [A, B] differs
+    from training on [B, B] and from [A, A]."""
+    d, x, obs_p, obs_v = load("train_f30_c16_r1")
+    F, C, R = int(d["features"]), int(d["filters"]), int(d["residuals"])
+    def run(xs, ps, vs, epochs, calls, batch):
+        nn = NN(8, 8, F, 4672, filters=C, residuals=R, dtype="f32")
+        nn.load_weights(d["blob"], 0)
+        for _ in range(calls):
+            nn.train(xs, ps, vs, mlr=5, epochs=epochs, batchsize=batch)
+        return nn.get_weights(), nn.get_generation()
+    w2, g2 = run(x, obs_p, obs_v, 2, 1, 8)
+    w11, g11 = run(x, obs_p, obs_v, 1, 2, 8)
+    assert g2 == 1 and g11 == 2
+    np.testing.assert_allclose(w2, w11, rtol=0, atol=1e-6)
+    A, B = slice(0, 4), slice(4, 8)
+    cat = lambda a, b: (np.concatenate([x[a], x[b]]), np.concatenate([obs_p[a], obs_p[b]]), np.concatenate([obs_v[a], obs_v[b]]))
+    wab, _ = run(*cat(A, B), 1, 1, 4)
+    wbb, _ = run(*cat(B, B), 1, 1, 4)
+    waa, _ = run(*cat(A, A), 1, 1, 4)
+    assert np.abs(wab - wbb).max() > 1e-4 and np.abs(wab - waa).max() > 1e-4
