@@ -413,6 +413,24 @@ def test_reference_programs_on_the_cpp_mirror(tmp_path):
     assert "Saved model to" in r.stdout
 
 
+def test_reference_nntrain_program_on_the_cpp_mirror(tmp_path):
+    """The reference's OWN test/nntrain.cpp (512 random trajectories through NN::train with the default
+    256-filter net, 8 epochs), compiled unmodified against the C++ mirror: runs to completion on the
+    device and reports a finite, decreasing loss."""
+    import os, re, subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(root, "oracle", "_ref", "dropin", "test_nntrain")
+    if not os.path.exists(exe):
+        pytest.skip("drop-in binaries not built (needs the reference tree at build time)")
+    r = subprocess.run([exe], cwd=tmp_path, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr + r.stdout
+    m = re.search(r"Generated model 1, average loss ([-0-9.e+]+) to ([-0-9.e+]+) over 8 epochs", r.stdout)
+    assert m, r.stdout
+    first, last = float(m.group(1)), float(m.group(2))
+    assert np.isfinite([first, last]).all() and last < first
+    assert "Finished in" in r.stdout
+
+
 # ------------------------------------------------------------------------------ full-size properties
 def test_full_size_properties_headline_config():
     """BASELINE configs[1] at its full size (512 x 119x8x8, 6x64), where the oracle is too slow to
