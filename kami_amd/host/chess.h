@@ -39,8 +39,13 @@ inline int popcount(uint64_t b) { return __builtin_popcountll(b); }
 constexpr uint64_t FILE_A = 0x0101010101010101ull, FILE_H = FILE_A << 7;
 constexpr uint64_t RANK_1 = 0xffull, RANK_8 = RANK_1 << 56;
 
+// direction order shared by the tables: N S E W NE NW SE SW (the action code's order too)
+constexpr int DIR_DR[8] = { 1, -1, 0, 0, 1, 1, -1, -1 };
+constexpr int DIR_DF[8] = { 0, 0, 1, -1, 1, -1, 1, -1 };
+
 struct Tables {
     uint64_t knight[64], king[64];
+    uint64_t ray[8][64];            // squares strictly beyond `sq` in a direction, to the board edge
     Tables()
     {
         for (int s = 0; s < 64; ++s) {
@@ -52,35 +57,35 @@ struct Tables {
             for (int dr = -1; dr <= 1; ++dr)
                 for (int df = -1; df <= 1; ++df)
                     if ((dr || df) && r + dr >= 0 && r + dr < 8 && f + df >= 0 && f + df < 8) king[s] |= bit((r + dr) * 8 + f + df);
+            for (int d = 0; d < 8; ++d) {
+                ray[d][s] = 0;
+                for (int rr = r + DIR_DR[d], ff = f + DIR_DF[d]; rr >= 0 && rr < 8 && ff >= 0 && ff < 8; rr += DIR_DR[d], ff += DIR_DF[d])
+                    ray[d][s] |= bit(rr * 8 + ff);
+            }
         }
     }
 };
 inline const Tables& tables() { static const Tables t; return t; }
 
-// squares a slider on `sq` reaches along (dr, df) directions until (and including) the first blocker
-inline uint64_t slide(int sq, uint64_t occ, const int (*dirs)[2], int ndirs)
+// squares a slider on `sq` reaches in direction d until (and including) the first blocker: the ray minus
+// the blocker's own ray (first blocker = lowest set bit for directions that increase the square index,
+// highest for the others)
+inline uint64_t ray_attacks(int d, int sq, uint64_t occ)
 {
-    uint64_t out = 0;
-    for (int d = 0; d < ndirs; ++d) {
-        int r = (sq >> 3) + dirs[d][0], f = (sq & 7) + dirs[d][1];
-        while (r >= 0 && r < 8 && f >= 0 && f < 8) {
-            const uint64_t b = bit(r * 8 + f);
-            out |= b;
-            if (occ & b) break;
-            r += dirs[d][0]; f += dirs[d][1];
-        }
-    }
-    return out;
+    const Tables& t = tables();
+    const uint64_t r = t.ray[d][sq], blockers = r & occ;
+    if (!blockers) return r;
+    const bool up = d == 0 || d == 2 || d == 4 || d == 5;       // N, E, NE, NW increase the index
+    const int b = up ? __builtin_ctzll(blockers) : 63 - __builtin_clzll(blockers);
+    return r ^ t.ray[d][b];
 }
 inline uint64_t rook_attacks(int sq, uint64_t occ)
 {
-    static const int d[4][2] = { { 1, 0 }, { -1, 0 }, { 0, 1 }, { 0, -1 } };
-    return slide(sq, occ, d, 4);
+    return ray_attacks(0, sq, occ) | ray_attacks(1, sq, occ) | ray_attacks(2, sq, occ) | ray_attacks(3, sq, occ);
 }
 inline uint64_t bishop_attacks(int sq, uint64_t occ)
 {
-    static const int d[4][2] = { { 1, 1 }, { 1, -1 }, { -1, 1 }, { -1, -1 } };
-    return slide(sq, occ, d, 4);
+    return ray_attacks(4, sq, occ) | ray_attacks(5, sq, occ) | ray_attacks(6, sq, occ) | ray_attacks(7, sq, occ);
 }
 
 struct Position {
@@ -228,14 +233,41 @@ struct Position {
         return n;
     }
 
+    // own pieces that stand alone between the king and an enemy slider aiming at it
+    uint64_t pinned() const
+    {
+        const int us = ctm, them = !ctm, k = king_sq(us);
+        const uint64_t o = occ();
+        const Tables& t = tables();
+        uint64_t pins = 0;
+        for (int d = 0; d < 8; ++d) {
+            const uint64_t sliders = (d < 4 ? (pc[ROOK] | pc[QUEEN]) : (pc[BISHOP] | pc[QUEEN])) & col[them];
+            if (!(t.ray[d][k] & sliders)) continue;
+            const uint64_t first = ray_attacks(d, k, o) & o;               // first blocker from the king
+            if (!(first & col[us])) continue;
+            const uint64_t second = ray_attacks(d, lsb(first), o) & o;     // the piece behind it
+            if (second & sliders) pins |= first;
+        }
+        return pins;
+    }
+
+    // legal moves: pseudo-legal ones that do not leave the king attacked.  Out of check, a move of an
+    // unpinned piece other than the king (and other than an en-passant capture, which removes a pawn
+    // beside the mover) cannot expose the king, so only the rest is played out and tested.
     int legal(Move* out) const
     {
         Move pl[MAX_MOVES];
         const int npl = pseudo_legal(pl);
+        const bool check = in_check();
+        const uint64_t pins = check ? ~0ull : pinned();
+        const int k = king_sq(ctm);
         int n = 0;
         for (int i = 0; i < npl; ++i) {
+            const Move m = pl[i];
+            const bool risky = check || m.src == k || (pins & bit(m.src)) || (ep >= 0 && m.dst == ep && (pc[PAWN] & bit(m.src)));
+            if (!risky) { out[n++] = m; continue; }
             Position q = *this;
-            if (q.make(pl[i])) out[n++] = pl[i];
+            if (q.make(m)) out[n++] = m;
         }
         return n;
     }

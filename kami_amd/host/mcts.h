@@ -2,7 +2,8 @@
 // same arithmetic (checked against the reference's own search in tests/golden/mcts_ref_*.txt), with
 // the two changes SURVEY §8f row 2 asks for:
 //   * trees live on the heap in per-tree node pools (the reference puts `MCTS trees[ibatch]` and
-//     per-call VLAs on the thread stack, selfplay.cpp:96, mcts.h:160), re-rooting keeps the chosen
+//     per-call VLAs on the thread stack, selfplay.cpp:96, mcts.h:160, and news / deletes every node);
+//     the children of a node are one contiguous block of the pool, re-rooting keeps the chosen
 //     subtree by moving it into a fresh pool;
 //   * several leaves of one tree can be in flight at once: select_leaf() marks the path with a
 //     virtual visit (n + 1, no reward) so that the next selection goes elsewhere, expand_leaf() takes
@@ -15,7 +16,6 @@
 #include "env.h"
 
 #include <cmath>
-#include <deque>
 #include <memory>
 #include <random>
 #include <stdexcept>
@@ -28,11 +28,16 @@ struct Node {                                   // mcts.h:14-64
     float w = 0.0f;
     float p = 0.0f;
     int action = -1;
-    std::vector<Node*> children;
+    Node* kids = nullptr;                       // children: one contiguous block (the reference: vector<Node*>)
+    int nkids = 0;
     Node* parent = nullptr;
     float turn = 0.0f;
     int inflight = 0;                           // virtual visits currently counted in n (this node and below)
     bool pending = false;                       // selected as a leaf, evaluation not back yet
+
+    struct Range { Node *b, *e; Node* begin() const { return b; } Node* end() const { return e; } size_t size() const { return (size_t)(e - b); }
+                   bool empty() const { return b == e; } };
+    Range children() const { return Range{ kids, kids + nkids }; }
 
     float q(float def = 1.0f) const { return n > 0 ? w / n : def; }
 
@@ -41,6 +46,22 @@ struct Node {                                   // mcts.h:14-64
         n += 1;
         w += 0.5f + (value * turn) / 2.0f;
         if (parent) parent->backprop(value);
+    }
+};
+
+// Node storage of one tree: fixed-size chunks, a node's children always inside one chunk.
+class NodePool {
+    static constexpr size_t CHUNK = 2048;
+    std::vector<std::unique_ptr<Node[]>> chunks;
+    size_t used = CHUNK;
+public:
+    Node* alloc(size_t count)
+    {
+        if (count > CHUNK) throw std::runtime_error("node block too large");
+        if (used + count > CHUNK) { chunks.emplace_back(new Node[CHUNK]); used = 0; }
+        Node* r = chunks.back().get() + used;
+        used += count;
+        return r;
     }
 };
 
@@ -64,7 +85,7 @@ public:
 
 private:
     Env env;
-    std::unique_ptr<std::deque<Node>> pool;
+    std::unique_ptr<NodePool> pool;
     Node* target = nullptr;                     // reference-shaped single-leaf API
     Leaf single;
     double cPUCT;
@@ -74,17 +95,13 @@ private:
     int scale_cpuct_by_actions;
     std::mt19937 rng;
 
-    Node* alloc() { pool->emplace_back(); return &pool->back(); }
-
-    Node* copy_subtree(const Node* src, Node* parent, std::deque<Node>& into)
+    void copy_subtree(const Node* src, Node* d, Node* parent, NodePool& into)
     {
-        into.emplace_back();
-        Node* d = &into.back();
         d->n = src->n; d->w = src->w; d->p = src->p; d->action = src->action; d->turn = src->turn;
         d->parent = parent;
-        d->children.reserve(src->children.size());
-        for (const Node* c : src->children) d->children.push_back(copy_subtree(c, d, into));
-        return d;
+        d->nkids = src->nkids;
+        d->kids = src->nkids ? into.alloc((size_t)src->nkids) : nullptr;
+        for (int i = 0; i < src->nkids; ++i) copy_subtree(src->kids + i, d->kids + i, d, into);
     }
 
     void mark(Node* leaf, int delta)            // virtual visit on the path leaf -> root
@@ -96,11 +113,11 @@ public:
     Node* root = nullptr;
 
     explicit MCTS(const MCTSConfig& c = MCTSConfig())
-        : pool(new std::deque<Node>()), cPUCT(c.cpuct), force_expand_unvisited(c.force_expand_unvisited != 0),
+        : pool(new NodePool()), cPUCT(c.cpuct), force_expand_unvisited(c.force_expand_unvisited != 0),
           unvisited_node_value((float)c.unvisited_node_value_pct / 100.0f), noise_weight(c.mcts_noise_weight),
           scale_cpuct_by_actions(c.scale_cpuct_by_actions), rng(c.seed)
     {
-        root = alloc();
+        root = pool->alloc(1);
         root->turn = -env.turn();               // mcts.h:82
     }
 
@@ -110,11 +127,12 @@ public:
     {
         if (root->inflight) throw std::runtime_error("push with leaves in flight");
         const Node* next = nullptr;
-        for (const Node* c : root->children)
-            if (c->action == action) next = c;
+        for (const Node& c : root->children())
+            if (c.action == action) next = &c;
         if (!next) throw std::runtime_error("no child for action");
-        std::unique_ptr<std::deque<Node>> fresh(new std::deque<Node>());
-        Node* r = copy_subtree(next, nullptr, *fresh);
+        std::unique_ptr<NodePool> fresh(new NodePool());
+        Node* r = fresh->alloc(1);
+        copy_subtree(next, r, nullptr, *fresh);
         pool = std::move(fresh);
         root = r;
         target = nullptr;
@@ -123,22 +141,23 @@ public:
 
     int pick(float alpha = 0.0f)                // mcts.h:139-181
     {
-        if (root->children.empty()) throw std::runtime_error("no children to pick from");
+        if (root->children().empty()) throw std::runtime_error("no children to pick from");
         if (alpha < 0.1f) {
             int best_n = 0, best_action = -1;
-            for (const Node* c : root->children)
-                if (c->n > best_n) { best_n = c->n; best_action = c->action; }
+            for (const Node& c : root->children())
+                if (c.n > best_n) { best_n = c.n; best_action = c.action; }
             return best_action;
         }
-        std::vector<double> dist(root->children.size());
+        double dist[chess::MAX_MOVES];
         double length = 0.0;
-        for (size_t i = 0; i < dist.size(); ++i) { dist[i] = std::pow(root->children[i]->n, 1.0f / alpha); length += dist[i]; }
+        const int nk = root->nkids;
+        for (int i = 0; i < nk; ++i) { dist[i] = std::pow(root->kids[i].n, 1.0f / alpha); length += dist[i]; }
         double ind = std::generate_canonical<double, 53>(rng);      // (the reference draws rand() / RAND_MAX)
-        for (size_t i = 0; i < dist.size(); ++i) {
+        for (int i = 0; i < nk; ++i) {
             ind -= dist[i] / length;
-            if (ind <= 0.0) return root->children[i]->action;
+            if (ind <= 0.0) return root->kids[i].action;
         }
-        return root->children.back()->action;
+        return root->kids[nk - 1].action;
     }
 
     // Walk from the root to a leaf by the reference's rule (mcts.h:183-259).  Returns true and fills `out`
@@ -152,7 +171,7 @@ public:
         int depth = 0;
         auto unwind = [&]() { for (; depth > 0; --depth) env.pop(); };
         for (;;) {
-            if (t->children.empty()) {
+            if (t->nkids == 0) {
                 if (t->pending) { unwind(); if (blocked) *blocked = true; return false; }
                 float value;
                 if (env.terminal(&value)) {
@@ -172,11 +191,13 @@ public:
             double best_uct = -1000.0;
             Node* best_child = nullptr;
             float cpuct = cPUCT;
-            if (scale_cpuct_by_actions) cpuct /= (float)t->children.size();
+            if (scale_cpuct_by_actions) cpuct /= (float)t->nkids;
             bool forced = false;
-            for (Node* c : t->children) {
+            const double sqrt_n = sqrt(t->n);          // the reference evaluates sqrt(target->n) per child: same value
+            for (Node& cn : t->children()) {
+                Node* c = &cn;
                 if (force_expand_unvisited && !c->n) { best_child = c; forced = true; break; }
-                double uct = c->q(unvisited_node_value * c->turn) + c->p * cpuct * sqrt(t->n) / (double)(c->n + 1);
+                double uct = c->q(unvisited_node_value * c->turn) + c->p * cpuct * sqrt_n / (double)(c->n + 1);
                 if (uct > best_uct) { best_child = c; best_uct = uct; }
             }
             (void)forced;
@@ -195,21 +216,30 @@ public:
         mark(t, -1);
         t->pending = false;
         const size_t na = leaf.actions.size();
-        std::vector<float> noise(na, 0.0f);
-        float total_noise = 0.0f;
-        for (size_t i = 0; i < na; ++i) {
-            std::gamma_distribution<> dist(1.0f, 1.0f);
-            noise[i] = dist(rng);
-            total_noise += noise[i];
+        // mcts.h:279-288 draws gamma(1, 1) noise for every action of every expansion; gamma(1, 1) IS the
+        // unit exponential, so -log(u) draws the same distribution at a fraction of the cost (and
+        // nothing is drawn when the weight is zero)
+        float noise[chess::MAX_MOVES];
+        float total_noise = 1.0f;
+        if (noise_weight != 0.0f) {
+            total_noise = 0.0f;
+            for (size_t i = 0; i < na; ++i) {
+                const float u = (float)((rng() >> 8) + 1) * (1.0f / 16777217.0f);      // (0, 1)
+                noise[i] = -std::log(u);
+                total_noise += noise[i];
+            }
+        } else {
+            for (size_t i = 0; i < na; ++i) noise[i] = 0.0f;
         }
-        t->children.reserve(na);
+        t->kids = na ? pool->alloc(na) : nullptr;
+        t->nkids = (int)na;
         for (size_t i = 0; i < na; ++i) {
-            Node* c = alloc();
+            Node* c = t->kids + i;
+            *c = Node();
             c->action = leaf.actions[i];
             c->parent = t;
             c->turn = -t->turn;
             c->p = (1 - noise_weight) * priors[i] + noise_weight * (noise[i] / total_noise);
-            t->children.push_back(c);
         }
         value *= t->turn;                       // mcts.h:304-310
         t->backprop(value);
@@ -249,8 +279,9 @@ public:
     {
         env = Env();
         target = nullptr;
-        pool.reset(new std::deque<Node>());
-        root = alloc();
+        pool.reset(new NodePool());
+        root = pool->alloc(1);
+        *root = Node();
         root->turn = -env.turn();
     }
 
@@ -258,12 +289,12 @@ public:
     void snapshot_sparse(std::vector<int>& actions, std::vector<float>& visits) const
     {
         actions.clear(); visits.clear();
-        for (const Node* c : root->children) { actions.push_back(c->action); visits.push_back((float)c->n / (float)(root->n - 1)); }
+        for (const Node& c : root->children()) { actions.push_back(c.action); visits.push_back((float)c.n / (float)(root->n - 1)); }
     }
     void snapshot(float* pspace) const          // mcts.h:341-348
     {
         for (int i = 0; i < PSIZE; ++i) pspace[i] = 0.0f;
-        for (const Node* c : root->children) pspace[c->action] = (float)c->n / (float)(root->n - 1);
+        for (const Node& c : root->children()) pspace[c.action] = (float)c.n / (float)(root->n - 1);
     }
 };
 

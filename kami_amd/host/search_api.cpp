@@ -143,8 +143,8 @@ int ks_mcts_synthetic(int nodes, int nmoves, int leaves, const int32_t* picks, i
             }
             snprintf(line, sizeof(line), "move %d fen %s\n", m, tree.get_env().print().c_str()); text += line;
             snprintf(line, sizeof(line), "root n %d w %.9g\n", tree.root->n, tree.root->w); text += line;
-            for (const Node* c : tree.root->children) {
-                snprintf(line, sizeof(line), "child %d n %d w %.9g p %.9g\n", c->action, c->n, c->w, c->p); text += line;
+            for (const Node& c : tree.root->children()) {
+                snprintf(line, sizeof(line), "child %d n %d w %.9g p %.9g\n", c.action, c.n, c.w, c.p); text += line;
             }
             const int picked = m < npicks ? picks[m] : tree.pick(0.0f);
             snprintf(line, sizeof(line), "pick %d\n", picked); text += line;
