@@ -431,6 +431,47 @@ def test_reference_nntrain_program_on_the_cpp_mirror(tmp_path):
     assert "Finished in" in r.stdout
 
 
+def test_reference_kami_program_full_cycle_on_the_cpp_mirror(tmp_path):
+    """The reference's OWN `kami` program (kami.cpp + selfplay.cpp + evaluate.cpp + mcts.h + env.h +
+    neocortex, compiled unmodified against the C++ mirror, no libtorch): self-play on its inference
+    threads through kh_infer, a trainer thread that clones the model, trains the clone (kh_train), gates
+    it against the current model (evaluate.cpp) and swaps it in through write() / read() — one full
+    generation on the device."""
+    import os, subprocess, time, threading
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(root, "oracle", "_ref", "dropin", "kami")
+    if not os.path.exists(exe):
+        pytest.skip("drop-in binaries not built (needs the reference tree at build time)")
+    opts = dict(filters=16, residuals=1, selfplay_batch=16, selfplay_nodes=16, inference_threads=2, training_threads=1,
+                replaybuffer_size=128, rpb_train_pct=40, training_sample_pct=60, training_epochs=2, training_batchsize=8,
+                training_mlr=5, evaluate_batch=8, evaluate_games=8, evaluate_nodes=8, evaluate_target_pct=0,
+                model_path=str(tmp_path / "model.bin"), engine_dtype="bf16")
+    (tmp_path / "options.yml").write_text("".join(f"{k}: {v}\n" for k, v in opts.items()))
+    proc = subprocess.Popen([exe], cwd=tmp_path, stdin=subprocess.PIPE, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    lines = []
+    t = threading.Thread(target=lambda: lines.extend(iter(proc.stdout.readline, "")), daemon=True)
+    t.start()
+    deadline = time.time() + 150
+    done = False
+    while time.time() < deadline and not done and proc.poll() is None:
+        time.sleep(1.0)
+        done = any("candidate accepted" in l or "candidate rejected" in l for l in lines)
+    try:
+        proc.stdin.write("status\nquit\n"); proc.stdin.flush()
+        proc.wait(timeout=60)
+    except Exception:
+        proc.kill()
+    out = "".join(lines)
+    assert done, out[-3000:]
+    assert "training generation 0" in out and "Generated model 1" in out, out[-3000:]
+    assert "evaluating model generation 1" in out
+    if "candidate accepted" in out:
+        assert "using new generation 1" in out and os.path.exists(tmp_path / "model.bin")
+    # the only complaint allowed is the start-up warning about the not-yet-existing model file (kami.cpp:46-49)
+    complaints = [l for l in out.splitlines() if "ERROR" in l or "failed" in l]
+    assert all("model read from" in l for l in complaints), complaints
+
+
 # ------------------------------------------------------------------------------ full-size properties
 def test_full_size_properties_headline_config():
     """BASELINE configs[1] at its full size (512 x 119x8x8, 6x64), where the oracle is too slow to
