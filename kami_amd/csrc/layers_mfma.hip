@@ -102,20 +102,25 @@ __device__ __forceinline__ void ring_issue(const char* stream, int nch, int c, i
 }
 
 // EPI: 0 = ReLU -> T;  1 = ReLU, + skip -> T (nn.cpp:31);  2 = raw fp32 logits, planes < 73 (nn.cpp:75-79)
-template <typename T, int TAPS, int EPI>
+// CPT = Ci / 64 (8 KB weight chunks per tap): a template parameter so that the whole chunk loop unrolls
+// with compile-time image offsets and register-set parity, like the tower kernel's layers — with a
+// run-time loop hipcc rotated the double buffer through v_mov copies and issued the next chunk's
+// activation reads (behind a run-time address computation) at the END of a step, exposing their
+// latency after every barrier: 2.6x the tower's time per step.
+template <typename T, int TAPS, int EPI, int CPT>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void conv_mfma_kernel(ConvArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     using V = typename Elem<T>::vec8;
     const int tid = threadIdx.x, lane = tid & 63, h = lane >> 5;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int Ci = a.Ci, Co = a.Co, KS = Ci / 16;          // Ci % 64 == 0: a chunk never straddles taps
-    const int stride = Ci * 2 + 16;
-    const int npx = (TAPS == 9) ? NPIX : 64;              // pixels per board image
-    const int board_bytes = npx * stride;
+    constexpr int Ci = CPT * 64;                           // a chunk never straddles taps
+    const int Co = a.Co;
+    constexpr int stride = Ci * 2 + 16;
+    constexpr int npx = (TAPS == 9) ? NPIX : 64;          // pixels per board image
+    constexpr int board_bytes = npx * stride;
     const int b0 = blockIdx.x * 2, cb = blockIdx.y;
-    const int CPT = KS / 4;                                // chunks per tap
-    const int NCH = TAPS * CPT;
+    constexpr int NCH = TAPS * CPT;
     const char* stream = reinterpret_cast<const char*>(a.w) + (size_t)cb * NCH * CHUNKB;
     char* img = smem + LDS_IMG;
 
@@ -126,7 +131,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     // ---- stage the two boards' input in LDS
     if (TAPS == 9) {
         const u32x4 z = { 0, 0, 0, 0 };
-        const int per_px = stride / 16;
+        constexpr int per_px = stride / 16;
         for (int i = tid; i < 2 * NPIX; i += 256) {
             const int pp = i % NPIX, yy = pp / PITCH, xx = pp % PITCH;
             if (yy >= 1 && yy <= 8 && xx >= 1 && xx <= 8) continue;
@@ -137,7 +142,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     {
         // 4 independent 16-byte loads in flight per thread, then their LDS writes (Ci % 64 == 0, so
         // the item count 2*64*Ci/8 is a multiple of 4*256)
-        const int CH = Ci / 8;
+        constexpr int CH = Ci / 8;
         for (int i0 = tid; i0 < 2 * 64 * CH; i0 += 4 * 256) {
             u32x4 v[4];
 #pragma unroll
@@ -170,8 +175,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             const float4 s = *reinterpret_cast<const float4*>(a.shift + cb * 64 + ms * 32 + 8 * g + 4 * h);
             acc[ms][4 * g + 0] = s.x; acc[ms][4 * g + 1] = s.y; acc[ms][4 * g + 2] = s.z; acc[ms][4 * g + 3] = s.w;
         }
-    // byte offset of the first k-step of chunk n in the image, relative to b_base
-    auto chunk_off = [&](int n) -> unsigned {
+    // byte offset of the first k-step of chunk n in the image, relative to b_base (a constant after unrolling)
+    auto chunk_off = [](int n) -> unsigned {
         const int tap = n / CPT, q = n - tap * CPT;
         return ((TAPS == 9) ? (unsigned)(((tap / 3) * PITCH + (tap % 3)) * stride) : 0u) + q * 128;
     };
@@ -183,34 +188,32 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 #pragma unroll
     for (int k = 0; k < 4; ++k) Bq[0][k] = *reinterpret_cast<const V*>(smem + b_base + chunk_off(0) + k * 32);
 
-    // one chunk step with register set CUR holding chunk n (see tower_mfma.hip for the protocol)
-#define KH_LAYER_STEP(CUR, n)                                                                          \
-    {                                                                                                  \
-        asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(2 * (RD - 3)) : "memory");               \
-        __builtin_amdgcn_sched_barrier(0);                                                             \
-        ring_issue(stream, NCH, (n) + RD - 1, wave, lane);                                             \
-        const unsigned a_off = (unsigned)((((n) + 1) % RD) * CHUNKB) + lane * 16;                      \
-        _Pragma("unroll") for (int f = 0; f < 8; ++f)                                                  \
-            A[(CUR) ^ 1][f] = *reinterpret_cast<const V*>(smem + a_off + f * 1024);                    \
-        const unsigned bo = chunk_off(((n) + 1 < NCH) ? (n) + 1 : (n));                                \
-        _Pragma("unroll") for (int k = 0; k < 4; ++k)                                                  \
-            Bq[(CUR) ^ 1][k] = *reinterpret_cast<const V*>(smem + b_base + bo + k * 32);                \
-        _Pragma("unroll") for (int k = 0; k < 4; ++k) {                                                \
-            acc[0] = Elem<T>::mfma(A[CUR][2 * k], Bq[CUR][k], acc[0]);                                 \
-            acc[1] = Elem<T>::mfma(A[CUR][2 * k + 1], Bq[CUR][k], acc[1]);                             \
-        }                                                                                              \
-        _Pragma("unroll") for (int i = 0; i < 8; ++i) {                                                \
-            __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);                                         \
-            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                         \
-        }                                                                                              \
+    // one chunk step per iteration, fully unrolled: register set n & 1 holds chunk n (see tower_mfma.hip
+    // for the ring protocol and the pinned read / MFMA interleave)
+#pragma unroll
+    for (int n = 0; n < NCH; ++n) {
+        const int cur = n & 1, nxt = cur ^ 1;
+        asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(2 * (RD - 3)) : "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        ring_issue(stream, NCH, n + RD - 1, wave, lane);
+        const unsigned a_off = (unsigned)(((n + 1) % RD) * CHUNKB) + lane * 16;
+#pragma unroll
+        for (int f = 0; f < 8; ++f) A[nxt][f] = *reinterpret_cast<const V*>(smem + a_off + f * 1024);
+        if (n + 1 < NCH) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) Bq[nxt][k] = *reinterpret_cast<const V*>(smem + b_base + chunk_off(n + 1) + k * 32);
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            acc[0] = Elem<T>::mfma(A[cur][2 * k], Bq[cur][k], acc[0]);
+            acc[1] = Elem<T>::mfma(A[cur][2 * k + 1], Bq[cur][k], acc[1]);
+        }
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        }
     }
-    int n = 0;
-    for (; n + 1 < NCH; n += 2) {
-        KH_LAYER_STEP(0, n)
-        KH_LAYER_STEP(1, n + 1)
-    }
-    if (n < NCH) KH_LAYER_STEP(0, n)
-#undef KH_LAYER_STEP
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // drain the ring (tail re-fetches) before exit
 
     // ---- epilogue
@@ -451,19 +454,30 @@ static hipError_t run_f32(const LayersArgs& L, hipStream_t s)
     return hipGetLastError();
 }
 
-template <typename T, int TAPS, int EPI> static hipError_t launch_conv(const ConvArgs& a, hipStream_t s)
+template <typename T, int TAPS, int EPI, int CPT> static hipError_t launch_conv_cpt(const ConvArgs& a, hipStream_t s)
 {
     const int stride = a.Ci * 2 + 16;
     const int lds = LDS_IMG + 2 * ((TAPS == 9) ? NPIX : 64) * stride;
     static bool attr_done = false;
     if (!attr_done) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_mfma_kernel<T, TAPS, EPI>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_mfma_kernel<T, TAPS, EPI, CPT>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) return e;
         attr_done = true;
     }
-    hipLaunchKernelGGL((conv_mfma_kernel<T, TAPS, EPI>), dim3((a.B + 1) / 2, a.Co / 64), dim3(256), lds, s, a);
+    hipLaunchKernelGGL((conv_mfma_kernel<T, TAPS, EPI, CPT>), dim3((a.B + 1) / 2, a.Co / 64), dim3(256), lds, s, a);
     return hipGetLastError();
+}
+
+template <typename T, int TAPS, int EPI> static hipError_t launch_conv(const ConvArgs& a, hipStream_t s)
+{
+    switch (a.Ci / 64) {                   // input channels are padded to a multiple of 64, at most 256
+    case 1: return launch_conv_cpt<T, TAPS, EPI, 1>(a, s);
+    case 2: return launch_conv_cpt<T, TAPS, EPI, 2>(a, s);
+    case 3: return launch_conv_cpt<T, TAPS, EPI, 3>(a, s);
+    case 4: return launch_conv_cpt<T, TAPS, EPI, 4>(a, s);
+    default: return hipErrorInvalidValue;
+    }
 }
 
 template <typename T> static hipError_t run(const LayersArgs& L, hipStream_t s)
