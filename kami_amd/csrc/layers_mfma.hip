@@ -140,24 +140,45 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         }
     }
     {
-        // 4 independent 16-byte loads in flight per thread, then their LDS writes (Ci % 64 == 0, so
-        // the item count 2*64*Ci/8 is a multiple of 4*256)
+        // A thread owns 4 loads of 16 bytes per 64 input channels.  Up to 128 channels: batches of four in
+        // flight, then their LDS writes; from 192 channels: all of them at once (one exposed memory
+        // latency for the whole image).  Measured on one device: all 16 at once is +5 % end to end at
+        // 256 channels, all 8 at once -22 % at 128 channels.
         constexpr int CH = Ci / 8;
-        for (int i0 = tid; i0 < 2 * 64 * CH; i0 += 4 * 256) {
-            u32x4 v[4];
+        if (CPT >= 3) {
+            constexpr int NL = 2 * 64 * CH / 256;
+            u32x4 v[NL];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int i = i0 + u * 256;
+            for (int u = 0; u < NL; ++u) {
+                const int i = tid + u * 256;
                 const int bb = i / (64 * CH), p = (i / CH) & 63, c = i % CH;
                 v[u] = u32x4{ 0, 0, 0, 0 };
                 if (b0 + bb < a.B) v[u] = *reinterpret_cast<const u32x4*>(a.in + ((size_t)(b0 + bb) * 64 + p) * Ci + c * 8);
             }
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int i = i0 + u * 256;
+            for (int u = 0; u < NL; ++u) {
+                const int i = tid + u * 256;
                 const int bb = i / (64 * CH), p = (i / CH) & 63, c = i % CH;
                 const int pix = (TAPS == 9) ? ((p >> 3) + 1) * PITCH + (p & 7) + 1 : p;
                 *reinterpret_cast<u32x4*>(img + bb * board_bytes + pix * stride + c * 16) = v[u];
+            }
+        } else {
+            for (int i0 = tid; i0 < 2 * 64 * CH; i0 += 4 * 256) {
+                u32x4 v[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int i = i0 + u * 256;
+                    const int bb = i / (64 * CH), p = (i / CH) & 63, c = i % CH;
+                    v[u] = u32x4{ 0, 0, 0, 0 };
+                    if (b0 + bb < a.B) v[u] = *reinterpret_cast<const u32x4*>(a.in + ((size_t)(b0 + bb) * 64 + p) * Ci + c * 8);
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int i = i0 + u * 256;
+                    const int bb = i / (64 * CH), p = (i / CH) & 63, c = i % CH;
+                    const int pix = (TAPS == 9) ? ((p >> 3) + 1) * PITCH + (p & 7) + 1 : p;
+                    *reinterpret_cast<u32x4*>(img + bb * board_bytes + pix * stride + c * 16) = v[u];
+                }
             }
         }
     }
