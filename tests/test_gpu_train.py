@@ -94,3 +94,27 @@ def test_train_epochs_compose_and_batches_are_distinct():
     wbb, _ = run(*cat(B, B), 1, 1, 4)
     waa, _ = run(*cat(A, A), 1, 1, 4)
     assert np.abs(wab - wbb).max() > 1e-4 and np.abs(wab - waa).max() > 1e-4
+
+
+@pytest.mark.gpu
+def test_selfplay_train_cycle_two_generations():
+    """Rows f1-f4 together on this stack (kami_amd/cycle.py): the pool plays on the engine, finished games
+    become replay records, kh_train turns them into the next generation, the pool keeps playing on it."""
+    from kami_amd import search as S, cycle
+    from kami_amd.replay import ReplayBuffer
+    F, C, R = 30, 32, 2
+    nn = NN(8, 8, F, 4672, filters=C, residuals=R, dtype="bf16", value_mode=L.KH_VALUE_PER_SAMPLE0)
+    nn.load_weights(W.random_weights(F, C, R, seed=21, peaky=3.0), 0)
+    pool = S.Pool(nn, games=256, threads=4, nodes=16, seed=7)
+    replay = ReplayBuffer(cycle.OBSIZE, cycle.PSIZE, 4096, seed=1)
+    p0, _ = nn.infer(np.zeros((1, 8, 8, 30), np.float32))
+    for gen in range(2):
+        out = cycle.generation(nn, pool, replay, play_evals=150000, play_seconds=60.0, epochs=2, batchsize=8, sample=256)
+        assert out["games_finished"] > 0 and out["records"] > 0
+        assert out["generation_after"] == gen + 1
+        assert np.isfinite([out["first_loss"], out["last_loss"]]).all() and out["last_loss"] < out["first_loss"]
+    p1, _ = nn.infer(np.zeros((1, 8, 8, 30), np.float32))
+    assert not np.array_equal(p0, p1)
+    # the records the trainer saw are real positions: 32 pieces or fewer, one king each
+    planes = replay.input_buffer[:replay.count()].reshape(-1, 64, 30)
+    assert (planes[:, :, 18:].sum((1, 2)) <= 32).all() and (planes[:, :, 23].sum(1) == 1).all() and (planes[:, :, 29].sum(1) == 1).all()
