@@ -239,34 +239,64 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 
     // ---- epilogue
     const int b = b0 + wb;
-    if (b >= a.B) return;
     const int p = py * 8 + px;
+    if (EPI == 2) {
+        if (b >= a.B) return;
+        float* lo = reinterpret_cast<float*>(a.out) + (size_t)b * KH_PSIZE + p * KH_POLICY_PLANES;
+#pragma unroll
+        for (int ms = 0; ms < 2; ++ms)
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int ch = cb * 64 + ms * 32 + 8 * g + 4 * h + i;
+                    if (ch < KH_POLICY_PLANES) lo[ch] = acc[ms][4 * g + i];
+                }
+        return;
+    }
+    // The C/D layout leaves 4 consecutive channels of a pixel per lane: written straight out that is 8
+    // scattered 8-byte stores per lane.  Transposed through LDS (the image is dead now) every lane
+    // gets 8 consecutive channels of a pixel instead: one 16-byte skip load and one 16-byte store per
+    // lane, 8 lanes covering a pixel's whole 128-byte line.
+    __syncthreads();                                        // everybody is done reading the image
+    constexpr int TSTR = 64 * 4 + 16;                       // fp32 row of one pixel + pad
+    char* tile = img + wave * 32 * TSTR;                    // this wave's 32 pixels x 64 channels
+    const int lr = lane & 31;                               // this lane's pixel column in the tile
 #pragma unroll
     for (int ms = 0; ms < 2; ++ms)
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
-            const int ch = cb * 64 + ms * 32 + 8 * g + 4 * h;
-            float v[4] = { acc[ms][4 * g], acc[ms][4 * g + 1], acc[ms][4 * g + 2], acc[ms][4 * g + 3] };
-            if (EPI == 2) {
-                float* lo = reinterpret_cast<float*>(a.out) + (size_t)b * KH_PSIZE + p * KH_POLICY_PLANES;
+            float4 v = make_float4(relu_keep_nan(acc[ms][4 * g]), relu_keep_nan(acc[ms][4 * g + 1]),
+                                   relu_keep_nan(acc[ms][4 * g + 2]), relu_keep_nan(acc[ms][4 * g + 3]));
+            *reinterpret_cast<float4*>(tile + lr * TSTR + (ms * 32 + 8 * g + 4 * h) * 4) = v;
+        }
+    // (same wave wrote it: LDS operations of a wave are ordered, no barrier needed)
+    if (b >= a.B) return;
 #pragma unroll
-                for (int i = 0; i < 4; ++i)
-                    if (ch + i < KH_POLICY_PLANES) lo[ch + i] = v[i];
-            } else {
-                const size_t o = ((size_t)b * 64 + p) * Co + ch;
+    for (int it = 0; it < 4; ++it) {
+        const int r = (lane >> 3) + 8 * it, c8 = (lane & 7) * 8;       // tile column r = pixel PIXMAP[r] of this wave's rows
+        const int lp2 = PIXMAP[r];
+        const int pix = (4 * (wave & 1) + (lp2 >> 3)) * 8 + (lp2 & 7);
+        const float4 lo = *reinterpret_cast<const float4*>(tile + r * TSTR + c8 * 4);
+        const float4 hi = *reinterpret_cast<const float4*>(tile + r * TSTR + c8 * 4 + 16);
+        float v[8] = { lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w };
+        const size_t o = ((size_t)b * 64 + pix) * Co + cb * 64 + c8;
+        if (EPI == 1) {
+            const u32x4 sk = *reinterpret_cast<const u32x4*>(a.skip + o);
+            const unsigned w4[4] = { sk.x, sk.y, sk.z, sk.w };
 #pragma unroll
-                for (int i = 0; i < 4; ++i) v[i] = relu_keep_nan(v[i]);
-                if (EPI == 1) {
-                    const u32x2 s = *reinterpret_cast<const u32x2*>(a.skip + o);
-                    v[0] += from_bits<T>((unsigned short)(s.x & 0xffff)); v[1] += from_bits<T>((unsigned short)(s.x >> 16));
-                    v[2] += from_bits<T>((unsigned short)(s.y & 0xffff)); v[3] += from_bits<T>((unsigned short)(s.y >> 16));
-                }
-                u32x2 r;
-                r.x = to_bits<T>(v[0]) | ((unsigned)to_bits<T>(v[1]) << 16);
-                r.y = to_bits<T>(v[2]) | ((unsigned)to_bits<T>(v[3]) << 16);
-                *reinterpret_cast<u32x2*>(reinterpret_cast<unsigned short*>(a.out) + o) = r;
+            for (int k = 0; k < 4; ++k) {
+                v[2 * k] += from_bits<T>((unsigned short)(w4[k] & 0xffff));
+                v[2 * k + 1] += from_bits<T>((unsigned short)(w4[k] >> 16));
             }
         }
+        u32x4 out;
+        out.x = to_bits<T>(v[0]) | ((unsigned)to_bits<T>(v[1]) << 16);
+        out.y = to_bits<T>(v[2]) | ((unsigned)to_bits<T>(v[3]) << 16);
+        out.z = to_bits<T>(v[4]) | ((unsigned)to_bits<T>(v[5]) << 16);
+        out.w = to_bits<T>(v[6]) | ((unsigned)to_bits<T>(v[7]) << 16);
+        *reinterpret_cast<u32x4*>(reinterpret_cast<unsigned short*>(a.out) + o) = out;
+    }
 }
 
 // valueconv + vbatchnorm + relu (nn.cpp:83-85) on T activations: one thread per (board, pixel)
@@ -478,7 +508,8 @@ static hipError_t run_f32(const LayersArgs& L, hipStream_t s)
 template <typename T, int TAPS, int EPI, int CPT> static hipError_t launch_conv_cpt(const ConvArgs& a, hipStream_t s)
 {
     const int stride = a.Ci * 2 + 16;
-    const int lds = LDS_IMG + 2 * ((TAPS == 9) ? NPIX : 64) * stride;
+    const int image = 2 * ((TAPS == 9) ? NPIX : 64) * stride, tiles = 4 * 32 * (64 * 4 + 16);   // the epilogue's transpose tiles reuse the image
+    const int lds = LDS_IMG + (image > tiles ? image : tiles);
     static bool attr_done = false;
     if (!attr_done) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_mfma_kernel<T, TAPS, EPI, CPT>),
