@@ -393,20 +393,34 @@ __global__ __launch_bounds__(256) void conv_f32_kernel(ConvArgsF32 a)
         x0 = *reinterpret_cast<const f32x4v*>(wp + (size_t)k * 512);
         x1 = *reinterpret_cast<const f32x4v*>(wp + (size_t)k * 512 + 256);
     };
-    f32x4v a0, a1, bq, a0n, a1n, bn;
-    ld(0, a0, a1, bq);
-    ld(1, a0n, a1n, bn);
-    for (int kk = 0; kk < TK; ++kk) {
-        f32x4v a0f, a1f, bf;
-        ld(kk + 2, a0f, a1f, bf);
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[i], bq[i], acc[0], 0, 0, 0);
-            acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[i], bq[i], acc[1], 0, 0, 0);
-        }
-        a0 = a0n; a1 = a1n; bq = bn;
-        a0n = a0f; a1n = a1f; bn = bf;
+    // Three operand sets in fixed roles (no register rotation): k-group kk multiplies out of set kk % 3
+    // while the loads of k-group kk + 2 land in set (kk + 2) % 3.  The loads are pinned to the top of
+    // each step — left alone hipcc sinks them down to their first use two steps later and every step
+    // then waits for a full L2 round trip.
+    f32x4v wa[3], wb2[3], xb[3];
+    ld(0, wa[0], wb2[0], xb[0]);
+    ld(1, wa[1], wb2[1], xb[1]);
+#define KH_F32_STEP(kk, CUR, NXT2)                                                                     \
+    {                                                                                                  \
+        __builtin_amdgcn_sched_barrier(0);                                                             \
+        ld((kk) + 2, wa[NXT2], wb2[NXT2], xb[NXT2]);                                                   \
+        _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                \
+            acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(wa[CUR][i], xb[CUR][i], acc[0], 0, 0, 0);    \
+            acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(wb2[CUR][i], xb[CUR][i], acc[1], 0, 0, 0);   \
+        }                                                                                              \
+        __builtin_amdgcn_sched_group_barrier(0x020, 2, 0);   /* the two weight loads */                \
+        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);   /* the activation read */                 \
+        __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);   /* then the MFMAs */                      \
     }
+    int kk = 0;
+    for (; kk + 2 < TK; kk += 3) {
+        KH_F32_STEP(kk, 0, 2)
+        KH_F32_STEP(kk + 1, 1, 0)
+        KH_F32_STEP(kk + 2, 2, 1)
+    }
+    if (kk < TK) { KH_F32_STEP(kk, 0, 2) ++kk; }
+    if (kk < TK) { KH_F32_STEP(kk, 1, 0) }
+#undef KH_F32_STEP
     const int b = b0 + wb;
     if (b >= a.B) return;
     const int p = py * 8 + px;
