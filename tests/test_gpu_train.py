@@ -118,3 +118,22 @@ def test_selfplay_train_cycle_two_generations():
     # the records the trainer saw are real positions: 32 pieces or fewer, one king each
     planes = replay.input_buffer[:replay.count()].reshape(-1, 64, 30)
     assert (planes[:, :, 18:].sum((1, 2)) <= 32).all() and (planes[:, :, 23].sum(1) == 1).all() and (planes[:, :, 29].sum(1) == 1).all()
+
+
+@pytest.mark.gpu
+def test_selfplay_train_cycle_two_ranks(tmp_path):
+    """SURVEY 8e + 8f rows 3/4 together: two evaluator ranks (sharing this box's GPU over gloo) play their
+    shards of the trees, rank 0 gathers both ranks' finished games, trains, and broadcasts generation 1."""
+    import json, os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    port = 29300 + os.getpid() % 500
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(root, "tests", "_cycle_worker.py"), str(tmp_path)]
+    subprocess.run(cmd, check=True, timeout=600, env=dict(os.environ, OMP_NUM_THREADS="1"), capture_output=True, text=True)
+    r = [json.load(open(tmp_path / f"rank{i}.json")) for i in range(2)]
+    assert r[0]["games"] + r[1]["games"] == 256
+    assert all(x["records"] > 0 and x["generation_before"] == 0 and x["generation_after"] == 1 for x in r)
+    assert r[0]["merged"] == r[1]["records"] and r[1]["merged"] == 0          # rank 1's games were inserted into the root's ring
+    assert r[0]["replay_count"] == r[0]["records"] + r[1]["records"]
+    assert r[0]["trained_on"] == 128 and "trained_on" not in r[1]
+    assert r[0]["wsum"] == r[1]["wsum"]                                                    # the broadcast reached rank 1
