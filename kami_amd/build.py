@@ -95,7 +95,7 @@ def build_search(force: bool = False, verbose: bool = False) -> str:
     srcs = [os.path.join(host, f) for f in ("search_api.cpp", "mcts.h", "env.h", "chess.h")]
     srcs += [os.path.join(os.path.dirname(HERE), "include", f) for f in ("kami_search.h", "kami_hip.h")]
     if force or _stale(SEARCH_LIB, srcs + [LIB]):
-        cmd = ["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-Wall", "-o", SEARCH_LIB, srcs[0],
+        cmd = ["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-Wall", "-I" + os.path.join(os.path.dirname(HERE), "include"), "-o", SEARCH_LIB, srcs[0],
                f"-L{HERE}", "-lkamihip", "-Wl,-rpath,$ORIGIN", "-lpthread"]
         if verbose:
             print(" ".join(cmd), flush=True)

@@ -11,7 +11,7 @@
 //   * pgn() (thc library) and bootstrap_value() (neocortex's static evaluation) are not part of this path.
 #pragma once
 #include "chess.h"
-#include "../../include/kami_hip.h"
+#include "kami_hip.h"           // include/ of this repository on the include path
 
 #include <string>
 #include <vector>

@@ -245,6 +245,13 @@ public:
         t->backprop(value);
     }
 
+    // give a selected leaf back unevaluated (its batch was full): only the virtual visit is undone
+    void release_leaf(Leaf& leaf)
+    {
+        mark(leaf.node, -1);
+        leaf.node->pending = false;
+    }
+
     // ---- the reference's one-leaf-at-a-time interface ------------------------------------------
     bool select(kh_board* obs)                  // mcts.h:183-259 (obs: compact record instead of planes)
     {

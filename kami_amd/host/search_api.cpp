@@ -1,7 +1,7 @@
 // search_api.cpp — libkamisearch.so: C ABI over env.h / mcts.h and the self-play pool that feeds the
 // engine (include/kami_search.h).  Host code only; the one device entry point it uses is
 // kh_encode_infer_legal.
-#include "../../include/kami_search.h"
+#include "kami_search.h"
 #include "mcts.h"
 
 #include <atomic>

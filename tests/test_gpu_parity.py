@@ -431,15 +431,20 @@ def test_reference_nntrain_program_on_the_cpp_mirror(tmp_path):
     assert "Finished in" in r.stdout
 
 
-def test_reference_kami_program_full_cycle_on_the_cpp_mirror(tmp_path):
-    """The reference's OWN `kami` program (kami.cpp + selfplay.cpp + evaluate.cpp + mcts.h + env.h +
-    neocortex, compiled unmodified against the C++ mirror, no libtorch): self-play on its inference
+@pytest.mark.parametrize("program", ["kami", "kami_native"])
+def test_reference_kami_program_full_cycle_on_the_cpp_mirror(tmp_path, program):
+    """`kami`: the reference's OWN program (kami.cpp + selfplay.cpp + evaluate.cpp + mcts.h + env.h +
+    neocortex, compiled unmodified against the C++ NN mirror, no libtorch): self-play on its inference
     threads through kh_infer, a trainer thread that clones the model, trains the clone (kh_train), gates
     it against the current model (evaluate.cpp) and swaps it in through write() / read() — one full
-    generation on the device."""
+    generation on the device.
+    `kami_native`: the same unmodified kami.cpp + options.cpp on THIS repository's whole host side
+    (kami_amd/host: selfplay, evaluate, mcts, env, chess rules, replay buffer, NN; no neocortex / thc):
+    the drop-in the north star describes — env.h / evaluate.h / selfplay.h surface kept, the search and the
+    worker pool ours, leaves sent as compact records through kh_encode_infer_legal."""
     import os, subprocess, time, threading
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    exe = os.path.join(root, "oracle", "_ref", "dropin", "kami")
+    exe = os.path.join(root, "oracle", "_ref", "dropin", program)
     if not os.path.exists(exe):
         pytest.skip("drop-in binaries not built (needs the reference tree at build time)")
     opts = dict(filters=16, residuals=1, selfplay_batch=16, selfplay_nodes=16, inference_threads=2, training_threads=1,
@@ -457,7 +462,7 @@ def test_reference_kami_program_full_cycle_on_the_cpp_mirror(tmp_path):
         time.sleep(1.0)
         done = any("candidate accepted" in l or "candidate rejected" in l for l in lines)
     try:
-        proc.stdin.write("status\nquit\n"); proc.stdin.flush()
+        proc.stdin.write("status\n" + ("pgn\n" if program == "kami_native" else "") + "quit\n"); proc.stdin.flush()
         proc.wait(timeout=60)
     except Exception:
         proc.kill()
@@ -470,6 +475,9 @@ def test_reference_kami_program_full_cycle_on_the_cpp_mirror(tmp_path):
     # the only complaint allowed is the start-up warning about the not-yet-existing model file (kami.cpp:46-49)
     complaints = [l for l in out.splitlines() if "ERROR" in l or "failed" in l]
     assert all("model read from" in l for l in complaints), complaints
+    assert "Total experiences:" in out
+    if program == "kami_native":
+        assert "[White \"KAMI generation" in out and (" 1-0 {" in out or " 0-1 {" in out or " 1/2-1/2 {" in out)
 
 
 # ------------------------------------------------------------------------------ full-size properties
