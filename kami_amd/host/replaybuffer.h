@@ -1,53 +1,61 @@
-// replaybuffer.h — mirror of kami::ReplayBuffer (kami/replaybuffer.h:10-92): a fixed ring of
-// (observation[obsize], mcts policy[psize], result) records under one mutex, uniform selection with
-// replacement over the whole ring.  Same public methods; storage in vectors.
-#pragma once
+// replaybuffer.h — kami::ReplayBuffer with the reference's public methods (kami/replaybuffer.h:10-92):
+// a fixed ring of (observation[obsize], mcts policy[psize], result) records under one mutex, uniform
+// selection with replacement over the whole ring (written or not).  Records are stored interleaved,
+// one contiguous row per record.
+#ifndef KAMI_AMD_HOST_REPLAYBUFFER_H
+#define KAMI_AMD_HOST_REPLAYBUFFER_H
 
+#include <algorithm>
 #include <cstdlib>
-#include <cstring>
 #include <mutex>
 #include <vector>
 
 namespace kami {
 
 class ReplayBuffer {
-    public:
-        ReplayBuffer(int obsize, int psize, int bufsize)
-            : obsize(obsize), psize(psize), bufsize(bufsize), input_buffer((size_t)obsize * bufsize),
-              mcts_buffer((size_t)psize * bufsize), result_buffer((size_t)bufsize) {}
+    const int obs_len, pol_len, capacity;
+    const size_t row;                       // floats per record: observation, policy, result
+    std::vector<float> ring;
+    std::mutex lock;
+    int head = 0;                           // next slot to write
+    long added = 0;                         // records ever added (the reference's `total`)
 
-        void clear() { total = 0; write_index = 0; }                        // replaybuffer.h:31-34
+public:
+    ReplayBuffer(int obsize, int psize, int bufsize)
+        : obs_len(obsize), pol_len(psize), capacity(bufsize), row((size_t)obsize + psize + 1), ring(row * (size_t)bufsize, 0.0f) {}
 
-        void add(const float* input, const float* mcts, float result)       // replaybuffer.h:36-56
-        {
-            std::lock_guard<std::mutex> lock(buffer_mut);
-            std::memcpy(&input_buffer[(size_t)write_index * obsize], input, sizeof(float) * obsize);
-            std::memcpy(&mcts_buffer[(size_t)write_index * psize], mcts, sizeof(float) * psize);
-            result_buffer[write_index++] = result;
-            write_index %= bufsize;
-            ++total;
+    int size() { return capacity; }
+    long count() { return added; }
+
+    void clear()
+    {
+        head = 0;
+        added = 0;
+    }
+
+    void add(const float* input, const float* mcts, float result)
+    {
+        std::lock_guard<std::mutex> hold(lock);
+        float* slot = ring.data() + row * (size_t)head;
+        std::copy(input, input + obs_len, slot);
+        std::copy(mcts, mcts + pol_len, slot + obs_len);
+        slot[obs_len + pol_len] = result;
+        head = (head + 1) % capacity;
+        ++added;
+    }
+
+    // n draws with replacement over ALL slots (replaybuffer.h:61-84: duplicates and never-written slots included)
+    void select_batch(float* dst_input, float* dst_mcts, float* dst_result, int n)
+    {
+        std::lock_guard<std::mutex> hold(lock);
+        for (int k = 0; k < n; ++k) {
+            const float* slot = ring.data() + row * (size_t)(rand() % capacity);
+            std::copy(slot, slot + obs_len, dst_input + (size_t)k * obs_len);
+            std::copy(slot + obs_len, slot + obs_len + pol_len, dst_mcts + (size_t)k * pol_len);
+            dst_result[k] = slot[obs_len + pol_len];
         }
-
-        int size() { return bufsize; }
-        long count() { return total; }
-
-        void select_batch(float* dst_input, float* dst_mcts, float* dst_result, int n)   // replaybuffer.h:61-84
-        {
-            std::lock_guard<std::mutex> lock(buffer_mut);
-            for (int i = 0; i < n; ++i) {
-                const int source = rand() % bufsize;
-                std::memcpy(dst_input + (size_t)i * obsize, &input_buffer[(size_t)source * obsize], sizeof(float) * obsize);
-                std::memcpy(dst_mcts + (size_t)i * psize, &mcts_buffer[(size_t)source * psize], sizeof(float) * psize);
-                dst_result[i] = result_buffer[source];
-            }
-        }
-
-    private:
-        int obsize, psize, bufsize;
-        std::mutex buffer_mut;
-        std::vector<float> input_buffer, mcts_buffer, result_buffer;
-        int write_index = 0;
-        long total = 0;
+    }
 };
 
 }  // namespace kami
+#endif

@@ -1,76 +1,61 @@
-// selfplay.h — mirror of kami::Selfplay (kami/selfplay.h:23-101): same public interface, so kami.cpp
-// (kami.cpp:53-54,124,147,189) compiles against it unchanged.  Inside, the inference threads run this
-// repository's search (mcts.h: heap trees, compact observations, legal-move priors from
-// kh_encode_infer_legal) instead of the reference's, and the trainer thread is selfplay.cpp:215-304 on
-// kami::NN::train = kh_train.
-#pragma once
+// selfplay.h — kami::Selfplay with the reference's public interface (kami/selfplay.h:23-101: constructor
+// from the model, start / stop, the status object, get_rbuf, get_next_pgn), so that kami.cpp
+// (kami.cpp:53-54,124,147,189) compiles against it unchanged.  Everything else lives behind one pointer
+// (selfplay.cpp): the inference threads run this repository's search (mcts.h: heap trees, compact
+// observations, legal-move priors from kh_encode_infer_legal), the trainer thread is
+// selfplay.cpp:215-304 on kami::NN::train = kh_train.
+#ifndef KAMI_AMD_HOST_SELFPLAY_H
+#define KAMI_AMD_HOST_SELFPLAY_H
 
 #include "nn/nn.h"
 #include "replaybuffer.h"
 
 #include <atomic>
-#include <chrono>
-#include <cstdint>
-#include <list>
+#include <memory>
 #include <mutex>
 #include <string>
-#include <thread>
-#include <vector>
 
 namespace kami {
 
 class Selfplay {
+public:
+    enum StatusCode { STOPPED, RUNNING, WAITING };
+
+    // Same two accessors as the reference's Status (selfplay.h:46-68): called without an argument they read,
+    // with one they set.  The code is an atomic here, only the message needs the lock.
+    class Status {
+        std::atomic<int> state{ STOPPED };
+        std::mutex guard;
+        std::string text;
     public:
-        Selfplay(NN* model);
-
-        void start();               // selfplay.cpp:21-35
-        void stop();                // selfplay.cpp:37-56
-
-        enum StatusCode { STOPPED, RUNNING, WAITING };
-
-        struct Status {             // selfplay.h:46-68
-            StatusCode _code = STOPPED;
-            std::mutex _lock;
-            std::string _message;
-
-            std::string message(std::string text = "")
-            {
-                std::lock_guard<std::mutex> lock(_lock);
-                if (!text.size()) return text;
-                return _message = text;
-            }
-            StatusCode code(int newcode = -1)
-            {
-                std::lock_guard<std::mutex> lock(_lock);
-                if (newcode < 0) return _code;
-                return _code = StatusCode(newcode);
-            }
-        };
-
-        Status status;
-        ReplayBuffer& get_rbuf() { return replay_buffer; }
-
-        std::string get_next_pgn()  // selfplay.h:73-80
+        StatusCode code(int newcode = -1)
         {
-            wants_pgn = true;
-            while (wants_pgn) std::this_thread::sleep_for(std::chrono::milliseconds(100));
-            return ret_pgn;
+            if (newcode >= 0) state.store(newcode);
+            return StatusCode(state.load());
         }
+        std::string message(std::string update = "")
+        {
+            if (update.empty()) return update;          // (the reference returns the empty argument, not the stored text)
+            std::lock_guard<std::mutex> hold(guard);
+            text = update;
+            return text;
+        }
+    };
 
-    private:
-        std::vector<std::thread> inference;
-        std::vector<std::thread> training;
-        NN* model;
-        ReplayBuffer replay_buffer;
-        int ibatch;
-        int nodes;
-        std::atomic<bool> wants_pgn;
-        std::string ret_pgn;
-        std::list<std::atomic<int>> partial_trajectories;
-        std::mutex partial_trajectories_lock;
+    explicit Selfplay(NN* model);
+    ~Selfplay();
 
-        void inference_main(int id);
-        void training_main(int id);
+    void start();
+    void stop();
+    ReplayBuffer& get_rbuf();
+    std::string get_next_pgn();          // blocks until an inference thread finishes a game
+
+    Status status;
+
+private:
+    struct Impl;
+    std::unique_ptr<Impl> impl;
 };
 
 }  // namespace kami
+#endif
