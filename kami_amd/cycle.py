@@ -2,7 +2,7 @@
 generation (kami/selfplay.cpp:58-304 without the gating match of evaluate.cpp).
 
     play      kami_amd.search.Pool          MCTS trees -> kh_encode_infer_legal           (rows f1, f2)
-    collect   ReplayBuffer (+ gather)       finished games' positions, merged over ranks  (row f3)
+    collect   gather_compact + ReplayBuffer finished games' positions, merged over ranks as 664-byte records (row f3)
     train     NN.train (kh_train)           the reference's SGD loop on the device        (row f4)
     publish   dist.broadcast_weights        every rank's evaluator gets the new generation (row f3)
 
@@ -34,11 +34,25 @@ def records_to_arrays(nn, records):
 def generation(nn, pool, replay: ReplayBuffer, *, play_evals: int, play_seconds: float = 60.0, sample: int | None = None,
                mlr: int = 5, epochs: int = 8, batchsize: int = 8, dist=None, device: str = "cpu"):
     """Play, collect, train (rank 0), publish.  Returns a dict of what happened."""
+    import ctypes as C
+    from . import search as S
+    from .replay import gather_compact
     st = pool.run(min_evals=play_evals, max_seconds=play_seconds)
-    planes, mcts, vals = records_to_arrays(nn, pool.drain())
-    for i in range(len(vals)):
-        replay.add(planes[i], mcts[i], float(vals[i]))                      # selfplay.cpp:176-184
-    merged = replay.gather(dist, root=0, device=device) if dist is not None else 0
+    mine = pool.drain()
+    # merge over the ranks as COMPACT records (664 B each); the root expands them (device encoder) into its ring
+    payload = b"".join(bytes(r) for r in mine)
+    merged = 0
+    rank0 = dist is None or dist.get_rank() == 0
+    for r, blob in enumerate(gather_compact(dist, payload, C.sizeof(S.Record), root=0, device=device)):
+        recs = (S.Record * (len(blob) // C.sizeof(S.Record))).from_buffer_copy(blob)
+        planes, mcts, vals = records_to_arrays(nn, recs)
+        for i in range(len(vals)):
+            replay.add(planes[i], mcts[i], float(vals[i]))                  # selfplay.cpp:176-184
+        if dist is not None and r != dist.get_rank():
+            merged += len(vals)
+    if not rank0:
+        merged = 0
+    vals = mine
     rank = dist.get_rank() if dist is not None else 0
     out = {"evals": st.evals, "games_finished": st.games_finished, "records": len(vals), "merged": merged,
            "generation_before": nn.get_generation()}

@@ -90,3 +90,30 @@ class ReplayBuffer:
                     inserted += 1
             self._fresh = []
         return inserted
+
+
+def gather_compact(dist, payload: bytes, record_bytes: int, root: int = 0, device: str = "cpu"):
+    """Merge fixed-size compact records (ks_record, 664 bytes: board + sparse visit distribution + value —
+    include/kami_search.h) over the ranks: 40x less traffic than the dense 26 372-byte rows `gather` moves.
+    Every rank passes its own records; returns the list of every rank's payload (rank-major) on `root`, and
+    [] elsewhere.  One size all-reduce + one all-gather of uint8 (RCCL over xGMI with device tensors, gloo
+    on CPU)."""
+    import torch
+    if dist is None:
+        return [payload]
+    world, rank = dist.get_world_size(), dist.get_rank()
+    assert len(payload) % record_bytes == 0
+    counts = torch.zeros(world, dtype=torch.int64, device=device)
+    counts[rank] = len(payload)
+    dist.all_reduce(counts)
+    nmax = int(counts.max().item())
+    if nmax == 0:
+        return [b""] * world if rank == root else []
+    pad = torch.zeros(nmax, dtype=torch.uint8, device=device)
+    if payload:
+        pad[:len(payload)] = torch.frombuffer(bytearray(payload), dtype=torch.uint8).to(device)
+    outs = [torch.empty_like(pad) for _ in range(world)]
+    dist.all_gather(outs, pad)
+    if rank != root:
+        return []
+    return [outs[r][:int(counts[r].item())].cpu().numpy().tobytes() for r in range(world)]

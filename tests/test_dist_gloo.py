@@ -62,3 +62,5 @@ def test_two_rank_gloo(tmp_path):
     ref = W.random_weights(30, 8, 1, seed=77)
     assert all(r["wgen"] == 41 and r["wn"] == ref.size for r in res)
     assert all(abs(r["wsum"] - float(ref.astype(np.float64).sum())) < 1e-9 for r in res)
+    # compact-record merge: rank-major on the root, nothing elsewhere
+    assert res[0]["compact"] == [list(range(0, 8)), list(range(10, 22))] and res[1]["compact"] == []
