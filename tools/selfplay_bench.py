@@ -7,7 +7,8 @@ F, C, R = 30, 64, 6
 nn = NN(8, 8, F, 4672, filters=C, residuals=R, dtype="bf16", value_mode=L.KH_VALUE_PER_SAMPLE0)
 nn.load_weights(W.random_weights(F, C, R, seed=1, peaky=5.0), 1)
 for games, threads, leaves, nodes in ((256, 1, 2, 800), (256, 4, 2, 800),      # BASELINE configs[1]: 256 games, 800 sims/move, batch-512 eval
-                                     (512, 1, 1, 64), (2048, 4, 1, 64), (2048, 8, 1, 64), (4096, 8, 1, 64), (1024, 8, 4, 64), (4096, 16, 1, 64)):
+                                     (512, 1, 1, 64), (2048, 4, 1, 64), (2048, 8, 1, 64), (4096, 8, 1, 64), (1024, 8, 4, 64), (4096, 16, 1, 64),
+                                     (8192, 32, 1, 64), (8192, 16, 1, 64)):     # more workers than cores: GPU waits of some hide under the search of others
     pool = S.Pool(nn, games=games, threads=threads, nodes=nodes, leaves_per_tree=leaves, seed=1)
     pool.run(min_evals=20000, max_seconds=10.0)          # warm-up
     s0 = pool.run(min_evals=0, max_seconds=0.0)
