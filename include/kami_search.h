@@ -66,6 +66,7 @@ typedef struct ks_pool_stats {
     int64_t games_finished, white_wins, black_wins, draws;
     int64_t records;            /* replay records produced                                                     */
     double  seconds, evals_per_s, mean_batch;
+    double  engine_seconds;     /* time the workers spent inside kh_encode_infer_legal, summed over workers     */
 } ks_pool_stats;
 
 /* one finished-game position: replaybuffer.h:20-22 holds OBSIZE + PSIZE + 1 floats (26 372 B) for this */

@@ -65,10 +65,19 @@ void launch_encode_f32(const kh_board* d_boards, int n, float* d_planes, hipStre
 __global__ __launch_bounds__(256) void gather_legal_kernel(const float* __restrict__ policy,
                                                            const int32_t* __restrict__ offsets,
                                                            const int32_t* __restrict__ actions,
-                                                           float* __restrict__ priors, int B)
+                                                           float* __restrict__ priors, int B,
+                                                           const float* __restrict__ vfull, int vstride,
+                                                           float* __restrict__ values, const int* __restrict__ flags_in,
+                                                           int* __restrict__ flags_out)
 {
     const int lane = threadIdx.x & 63;
     const int wpb = blockDim.x >> 6;
+    // the host path's compact results: one value per position and the NaN flags behind the priors, so
+    // that one copy brings everything back
+    if (values) {
+        for (int b = blockIdx.x * blockDim.x + threadIdx.x; b < B; b += gridDim.x * blockDim.x) values[b] = vfull[(size_t)b * vstride];
+        if (blockIdx.x == 0 && threadIdx.x < 4) flags_out[threadIdx.x] = flags_in[threadIdx.x];
+    }
     for (int b = blockIdx.x * wpb + (threadIdx.x >> 6); b < B; b += gridDim.x * wpb) {
         const int lo = offsets[b], hi = offsets[b + 1];
         const float* p = policy + (size_t)b * KH_PSIZE;
@@ -88,12 +97,14 @@ __global__ __launch_bounds__(256) void gather_legal_kernel(const float* __restri
 }
 
 void launch_gather_legal(const float* policy, const int32_t* offsets, const int32_t* actions,
-                         float* priors, int B, hipStream_t s)
+                         float* priors, int B, hipStream_t s, const float* vfull, int vstride, float* values,
+                         const int* flags_in, int* flags_out)
 {
     if (B <= 0) return;
     int blocks = (B + 3) / 4;
     if (blocks > 2048) blocks = 2048;
-    hipLaunchKernelGGL(gather_legal_kernel, dim3(blocks), dim3(256), 0, s, policy, offsets, actions, priors, B);
+    hipLaunchKernelGGL(gather_legal_kernel, dim3(blocks), dim3(256), 0, s, policy, offsets, actions, priors, B, vfull, vstride, values,
+                       flags_in, flags_out);
 }
 
 }  // namespace kh

@@ -58,6 +58,23 @@ struct DevMem {
     template <class T> T* as() const { return static_cast<T*>(p); }
 };
 
+// page-locked host staging: one DMA per direction instead of one driver-staged copy per argument
+struct PinMem {
+    void* p = nullptr;
+    size_t bytes = 0;
+    ~PinMem() { if (p) (void)hipHostFree(p); }
+    int ensure(size_t n)
+    {
+        if (n <= bytes) return KH_OK;
+        if (p) { (void)hipHostFree(p); p = nullptr; bytes = 0; }
+        n += n / 2;                              // action counts vary from call to call
+        HIPCHK(hipHostMalloc(&p, n, hipHostMallocDefault));
+        bytes = n;
+        return KH_OK;
+    }
+    char* at(size_t off) const { return static_cast<char*>(p) + off; }
+};
+
 // ------------------------------------------------------------------------------- weights
 // Host view of the canonical blob (order documented at kh_weight_count in kami_hip.h).
 struct ConvBN { const float *w, *b, *g, *be, *rm, *rv; };
@@ -357,6 +374,8 @@ struct Slot {
     hipStream_t stream = nullptr;
     int cap = 0;                 // boards the scratch is sized for
     DevMem in, x, t, u, ph, logits, policy, v64, vfull, flags, boards, planes, offs, acts, priors, actin;
+    DevMem pack_in, pack_out;    // legal-move host path: arguments / results packed for one copy each way
+    PinMem hin, hout;
     bool busy = false;
     bool flags_clean = false;    // device NaN flags known to be zero
 };
@@ -378,7 +397,7 @@ struct kh_engine {
 
 namespace {
 
-constexpr int MAX_SLOTS = 8;
+constexpr int MAX_SLOTS = 32;
 
 int set_device(kh_engine* e) { HIPCHK(hipSetDevice(e->cfg.device)); return KH_OK; }
 
@@ -588,19 +607,56 @@ int infer_host(kh_engine* e, const float* input, const kh_board* boards, int bat
     hipStream_t st = s.stream;
     const float* d_in;
     const bool fused = boards && fused_ingest(e, *W) && !logits;
+    // The search's call (records or planes in, legal priors + one value per position out): everything
+    // but the planes travels as ONE page-locked block per direction.
+    const bool packed = legal && value && !policy && !logits && !value_full;
+    auto up16 = [](size_t n) { return (n + 15) & ~(size_t)15; };
+    const size_t in_boards = 0, in_offs = boards ? up16(B * sizeof(kh_board)) : 0, in_acts = in_offs + up16((B + 1) * 4),
+                 in_total = in_acts + up16((size_t)nact * 4);
+    const size_t out_priors = 0, out_values = up16((size_t)nact * 4), out_flags = out_values + up16(B * 4), out_total = out_flags + 16;
+    const kh_board* d_boards = s.boards.as<kh_board>();
+    if (packed) {
+        if (s.hin.ensure(in_total) || s.hout.ensure(out_total)) return KH_ERR_HIP;
+        if (s.pack_in.ensure(s.hin.bytes) || s.pack_out.ensure(s.hout.bytes)) return KH_ERR_HIP;
+        if (boards) memcpy(s.hin.at(in_boards), boards, B * sizeof(kh_board));
+        memcpy(s.hin.at(in_offs), legal->offsets, (B + 1) * 4);
+        memcpy(s.hin.at(in_acts), legal->actions, (size_t)nact * 4);
+        HIPCHK(hipMemcpyAsync(s.pack_in.p, s.hin.p, in_total, hipMemcpyHostToDevice, st));
+        d_boards = reinterpret_cast<const kh_board*>(s.pack_in.as<char>() + in_boards);
+    }
     if (boards) {
-        HIPCHK(hipMemcpyAsync(s.boards.p, boards, B * sizeof(kh_board), hipMemcpyHostToDevice, st));
-        if (!fused) kh::launch_encode_f32(s.boards.as<kh_board>(), batch, s.planes.as<float>(), st);
+        if (!packed) HIPCHK(hipMemcpyAsync(s.boards.p, boards, B * sizeof(kh_board), hipMemcpyHostToDevice, st));
+        if (!fused) kh::launch_encode_f32(d_boards, batch, s.planes.as<float>(), st);
         d_in = s.planes.as<float>();
     } else {
         HIPCHK(hipMemcpyAsync(s.in.p, input, B * 64 * F * 4, hipMemcpyHostToDevice, st));   // nn.cpp:160
         d_in = s.in.as<float>();
     }
     float* d_logits = logits ? s.logits.as<float>() : nullptr;
-    if (fused) rc = forward_tower(e, *W, s, nullptr, batch, s.policy.as<float>(), s.vfull.as<float>(), nullptr, s.boards.as<kh_board>());
+    if (fused) rc = forward_tower(e, *W, s, nullptr, batch, s.policy.as<float>(), s.vfull.as<float>(), nullptr, d_boards);
     else rc = forward_dispatch(e, *W, s, d_in, batch, s.policy.as<float>(), s.vfull.as<float>(), d_logits);
     if (rc) return rc;
     int flags[4] = { 0, 0, 0, 0 };
+    if (packed) {
+        const char* pin = s.pack_in.as<char>();
+        char* pout = s.pack_out.as<char>();
+        // nn.cpp:186 hands back the first `batch` floats of the flattened [batch,256] tensor; the fixed mode the value column
+        const int vstride = e->cfg.value_mode == KH_VALUE_REFERENCE_FLAT ? 1 : KH_VALUE_WIDTH;
+        kh::launch_gather_legal(s.policy.as<float>(), reinterpret_cast<const int32_t*>(pin + in_offs),
+                                reinterpret_cast<const int32_t*>(pin + in_acts), reinterpret_cast<float*>(pout + out_priors), batch, st,
+                                s.vfull.as<float>(), vstride, reinterpret_cast<float*>(pout + out_values), s.flags.as<int>(),
+                                reinterpret_cast<int*>(pout + out_flags));
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipMemcpyAsync(s.hout.p, s.pack_out.p, out_total, hipMemcpyDeviceToHost, st));
+        HIPCHK(hipStreamSynchronize(st));
+        memcpy(legal->priors, s.hout.at(out_priors), (size_t)nact * 4);
+        memcpy(value, s.hout.at(out_values), B * 4);
+        memcpy(flags, s.hout.at(out_flags), 16);
+        if (flags[0] | flags[1]) s.flags_clean = false;
+        if (flags[0]) return fail(KH_ERR_NAN_POLICY, "inference policy output contains NaN");   // nn.cpp:176-177
+        if (flags[1]) return fail(KH_ERR_NAN_VALUE, "inference value output contains NaN");     // nn.cpp:179-180
+        return KH_OK;
+    }
     if (legal && nact > 0) {
         if (s.offs.ensure((B + 1) * 4) || s.acts.ensure((size_t)nact * 4) || s.priors.ensure((size_t)nact * 4)) return KH_ERR_HIP;
         HIPCHK(hipMemcpyAsync(s.offs.p, legal->offsets, (B + 1) * 4, hipMemcpyHostToDevice, st));

@@ -15,7 +15,8 @@ void launch_encode_f32(const kh_board* d_boards, int n, float* d_planes, hipStre
 
 // priors[k] = policy[i][actions[k]] / sum over position i's actions (mcts.h:273-276); one wave per position
 void launch_gather_legal(const float* policy, const int32_t* offsets, const int32_t* actions,
-                         float* priors, int B, hipStream_t s);
+                         float* priors, int B, hipStream_t s, const float* vfull = nullptr, int vstride = 0,
+                         float* values = nullptr, const int* flags_in = nullptr, int* flags_out = nullptr);
 
 // ---- forward_simple.hip -----------------------------------------------------------------
 // Plain fp32 VALU kernels, one launch per layer.  Exact-order fp32 (same tap-major,

@@ -116,6 +116,11 @@ struct Position {
             if (pc[t] & b) return t;
         return -1;
     }
+    // the same for a square known to be occupied, without branches
+    int type_at(int sq) const
+    {
+        return (int)(((pc[1] >> sq) & 1) + 2 * ((pc[2] >> sq) & 1) + 3 * ((pc[3] >> sq) & 1) + 4 * ((pc[4] >> sq) & 1) + 5 * ((pc[5] >> sq) & 1));
+    }
 
     // is `sq` attacked by a piece of colour `by`?
     bool attacked(int sq, int by) const
@@ -137,24 +142,28 @@ struct Position {
     // what a repetition compares (position.c:302-311): placement, en-passant square, castle rights, side
     uint64_t key() const
     {
-        uint64_t h = 0x9e3779b97f4a7c15ull;
-        auto mix = [&](uint64_t v) { h ^= v + 0x9e3779b97f4a7c15ull + (h << 6) + (h >> 2); h *= 0xff51afd7ed558ccdull; h ^= h >> 33; };
-        for (int t = 0; t < 6; ++t) mix(pc[t]);
-        mix(col[0]);
-        mix(((uint64_t)(uint8_t)ep << 16) | ((uint64_t)castle << 8) | ctm);
+        // six independent multiplies (no chain from one word to the next: the search computes a key per
+        // move of every walk), folded and finished with one avalanche step
+        const uint64_t a = (pc[0] + 0x9e3779b97f4a7c15ull) * 0xff51afd7ed558ccdull, b = (pc[1] + 0xc2b2ae3d27d4eb4full) * 0xc4ceb9fe1a85ec53ull,
+                       c = (pc[2] + 0x165667b19e3779f9ull) * 0x9fb21c651e98df25ull, d = (pc[3] + 0x27d4eb2f165667c5ull) * 0xd6e8feb86659fd93ull,
+                       e = (pc[4] + 0x85ebca77c2b2ae63ull) * 0xbf58476d1ce4e5b9ull, f = (pc[5] + 0x2545f4914f6cdd1dull) * 0x94d049bb133111ebull,
+                       g = (col[0] + 0x632be59bd9b4e019ull) * 0xe7037ed1a0b428dbull,
+                       m = ((((uint64_t)(uint8_t)ep << 16) | ((uint64_t)castle << 8) | ctm) + 0x3c79ac492ba7b653ull) * 0x1c69b3f74ac4ae35ull;
+        auto rot = [](uint64_t v, int r) { return (v << r) | (v >> (64 - r)); };
+        uint64_t h = a ^ rot(b, 9) ^ rot(c, 18) ^ rot(d, 27) ^ rot(e, 36) ^ rot(f, 45) ^ rot(g, 54) ^ rot(m, 31);
+        h ^= h >> 32; h *= 0xd6e8feb86659fd93ull; h ^= h >> 32;
         return h;
     }
 
     void remove(int sq, int type, int c) { pc[type] &= ~bit(sq); col[c] &= ~bit(sq); }
     void place(int sq, int type, int c) { pc[type] |= bit(sq); col[c] |= bit(sq); }
 
-    // Apply a pseudo-legal move (position.c:167-318 bookkeeping).  Returns false when it leaves the mover's
-    // king attacked (the position is then garbage for the caller's purposes).
-    bool make(Move m)
+    // Apply a pseudo-legal move (position.c:167-318 bookkeeping); apply() does not look at the mover's king.
+    void apply(Move m)
     {
         const int us = ctm, them = !ctm;
-        const int type = piece_at(m.src);
-        const int victim = (col[them] & bit(m.dst)) ? piece_at(m.dst) : -1;
+        const int type = type_at(m.src);
+        const int victim = (col[them] & bit(m.dst)) ? type_at(m.dst) : -1;
         ++halfmove;
         if (us == BLACK) ++fullmove;
         const int old_ep = ep;
@@ -180,7 +189,13 @@ struct Position {
         if (touched & (bit(60) | bit(56))) castle &= ~CASTLE_BQ;
         if (type == PAWN && std::abs((m.dst >> 3) - (m.src >> 3)) > 1) ep = (int8_t)(us == WHITE ? m.dst - 8 : m.dst + 8);
         ctm = (uint8_t)them;
-        return !attacked(king_sq(us), them);
+    }
+    // ... and make() says whether it left the mover's king attacked (the position is then garbage for the caller)
+    bool make(Move m)
+    {
+        const int us = ctm;
+        apply(m);
+        return !attacked(king_sq(us), !us);
     }
 
     // pseudo-legal moves of the side to move
@@ -350,7 +365,7 @@ struct Position {
 inline int encode_action(const Position& p, Move m)
 {
     int src = m.src, dst = m.dst;
-    const int type = p.piece_at(m.src);
+    const int type = p.type_at(m.src);
     if (p.ctm == BLACK) { src = 63 - src; dst = 63 - dst; }
     const int dr = (dst >> 3) - (src >> 3), df = (dst & 7) - (src & 7);
     if (type == PAWN && m.promo && m.promo != QUEEN) {

@@ -52,7 +52,7 @@ public:
     void push(int action)                                                    // env.h:264-271
     {
         chess::Position p = position();
-        p.make(decode(action));
+        p.apply(decode(action));                                             // (the reference does not test legality here either)
         stack.push_back({ p, p.key() });
         curturn = -curturn;
         actions_utd = false;
@@ -68,8 +68,10 @@ public:
     // earlier plies with the current position's key (ncPositionRepCount, position.c:1347-1357)
     int rep_count() const
     {
+        // a pawn move or capture cannot be undone, so nothing before the last one can equal the current position
+        const size_t n = stack.size(), span = std::min<size_t>(n - 1, (size_t)stack.back().pos.halfmove);
         int c = 0;
-        for (size_t i = 0; i + 1 < stack.size(); ++i) c += stack[i].key == stack.back().key;
+        for (size_t i = n - 1 - span; i + 1 < n; ++i) c += stack[i].key == stack.back().key;
         return c;
     }
 
@@ -97,6 +99,8 @@ public:
         return true;
     }
     bool terminal(float* value) { std::string unused; return terminal_str(value, unused); }   // env.h:386-390
+
+    void prefetch() const { __builtin_prefetch(&stack.back()); __builtin_prefetch(reinterpret_cast<const char*>(&stack.back()) + 64); }
 
     float turn() const { return curturn; }                                   // env.h:392-395
 

@@ -125,9 +125,9 @@ int ks_mcts_synthetic(int nodes, int nmoves, int leaves, const int32_t* picks, i
                 for (int j = 0; j < nb; ++j) {
                     // the evaluator sees the leaf position: rebuild its FEN by replaying the path
                     std::vector<int> path;
-                    for (Node* x = batch[j].node; x->parent; x = x->parent) path.push_back(x->action);
+                    for (size_t d = 1; d < batch[j].path.size(); ++d) path.push_back(batch[j].path[d]->action);
                     Env& e = tree.get_env();
-                    for (auto it = path.rbegin(); it != path.rend(); ++it) e.push(*it);
+                    for (int a : path) e.push(a);
                     const uint64_t h = fnv1a(e.print());
                     for (size_t k = 0; k < path.size(); ++k) e.pop();
                     double sum = 0.0;
@@ -170,11 +170,13 @@ struct ks_pool {
         std::unique_ptr<MCTS> tree;
         struct Step { kh_board board; std::vector<int> actions; std::vector<float> visits; float pov; };
         std::vector<Step> trajectory;
-        std::vector<MCTS::Leaf> leaves;     // in flight
+        std::vector<MCTS::Leaf> leaves;     // leaves[0 .. nleaves) are in flight (the objects are kept: their vectors keep their memory)
+        int nleaves = 0;
     };
     std::vector<Game> games;
     std::mutex rec_mutex;
     std::vector<ks_record> records;
+    std::atomic<int64_t> engine_ns{ 0 };
     std::atomic<int64_t> evals{ 0 }, batches{ 0 }, moves{ 0 }, finished{ 0 }, wwins{ 0 }, bwins{ 0 }, draws{ 0 }, nrecords{ 0 };
     double seconds = 0.0;
     std::string error;
@@ -249,31 +251,33 @@ void worker(ks_pool* p, int g0, int g1, int64_t target_evals, double deadline_s,
             for (int gi = g0; gi < g1; ++gi) {
                 ks_pool::Game& g = p->games[gi];
                 MCTS& tree = *g.tree;
-                g.leaves.clear();
+                if (gi + 2 < g1) p->games[gi + 2].tree->prefetch();     // a worker's trees do not fit its caches
+                if ((int)g.leaves.size() < L) g.leaves.resize((size_t)L);
+                g.nleaves = 0;
                 for (;;) {
-                    const int inflight = (int)g.leaves.size();
-                    if (inflight == 0 && tree.n() >= p->cfg.nodes) { advance_game(p, g); continue; }
-                    if (inflight >= L || tree.n() + inflight >= p->cfg.nodes) break;
-                    g.leaves.emplace_back();
+                    if (g.nleaves == 0 && tree.n() >= p->cfg.nodes) { advance_game(p, g); continue; }
+                    if (g.nleaves >= L || tree.n() + g.nleaves >= p->cfg.nodes) break;
                     bool blocked = false;
-                    if (tree.select_leaf(&g.leaves.back(), &blocked)) continue;
-                    g.leaves.pop_back();
+                    if (tree.select_leaf(&g.leaves[g.nleaves], &blocked)) { ++g.nleaves; continue; }
                     if (blocked) break;
                 }
-                for (size_t j = 0; j < g.leaves.size(); ++j) {
+                for (int j = 0; j < g.nleaves; ++j) {
                     boards.push_back(g.leaves[j].record);
                     actions.insert(actions.end(), g.leaves[j].actions.begin(), g.leaves[j].actions.end());
                     offsets.push_back((int32_t)actions.size());
-                    owner.emplace_back(gi, (int)j);
+                    owner.emplace_back(gi, j);
                 }
             }
             const int nb = (int)boards.size();
             if (nb == 0) continue;
             priors.resize(actions.size());
             values.resize((size_t)nb);
+            const auto e0 = std::chrono::steady_clock::now();
             const int rc = kh_encode_infer_legal(p->engine, boards.data(), nb, offsets.data(), actions.data(), priors.data(), values.data());
+            p->engine_ns += std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - e0).count();
             if (rc != KH_OK) throw std::runtime_error(std::string("kh_encode_infer_legal: ") + kh_last_error());
             for (int j = 0; j < nb; ++j) {
+                if (j + 2 < nb) { ks_pool::Game& a = p->games[owner[j + 2].first]; a.tree->prefetch_expand(a.leaves[owner[j + 2].second]); }
                 ks_pool::Game& g = p->games[owner[j].first];
                 g.tree->expand_leaf(g.leaves[owner[j].second], priors.data() + offsets[j], values[j]);
             }
@@ -328,6 +332,7 @@ int ks_pool_run(ks_pool* p, int64_t min_evals, double max_seconds, ks_pool_stats
         stats->seconds = p->seconds;
         stats->evals_per_s = p->seconds > 0 ? (double)p->evals / p->seconds : 0.0;
         stats->mean_batch = p->batches ? (double)p->evals / (double)p->batches : 0.0;
+        stats->engine_seconds = 1e-9 * (double)p->engine_ns;
     }
     return 0;
 }

@@ -30,7 +30,8 @@ class PoolConfig(C.Structure):
 class PoolStats(C.Structure):
     _fields_ = [("evals", C.c_int64), ("batches", C.c_int64), ("moves", C.c_int64), ("games_finished", C.c_int64),
                 ("white_wins", C.c_int64), ("black_wins", C.c_int64), ("draws", C.c_int64), ("records", C.c_int64),
-                ("seconds", C.c_double), ("evals_per_s", C.c_double), ("mean_batch", C.c_double)]
+                ("seconds", C.c_double), ("evals_per_s", C.c_double), ("mean_batch", C.c_double),
+                ("engine_seconds", C.c_double)]
 
 
 class Record(C.Structure):
