@@ -280,11 +280,18 @@ void worker(ks_pool* p, int g0, int g1, int64_t target_evals, double deadline_s,
                 if (j + 2 < nb) { ks_pool::Game& a = p->games[owner[j + 2].first]; a.tree->prefetch_expand(a.leaves[owner[j + 2].second]); }
                 ks_pool::Game& g = p->games[owner[j].first];
                 g.tree->expand_leaf(g.leaves[owner[j].second], priors.data() + offsets[j], values[j]);
+                if (owner[j].second + 1 == g.nleaves) g.nleaves = 0;       // nleaves > 0 <=> leaves marked in the tree
             }
             p->evals += nb;
             p->batches += 1;
         }
     } catch (std::exception& e) {
+        // a failed engine call must not leave virtual visits behind: the pool can be run again
+        for (int gi = g0; gi < g1; ++gi) {
+            ks_pool::Game& g = p->games[gi];
+            for (int j = 0; j < g.nleaves; ++j) g.tree->release_leaf(g.leaves[j]);
+            g.nleaves = 0;
+        }
         std::lock_guard<std::mutex> lk(p->err_mutex);
         p->error = e.what();
     }
@@ -315,6 +322,7 @@ int ks_pool_run(ks_pool* p, int64_t min_evals, double max_seconds, ks_pool_stats
 {
     const auto t0 = std::chrono::steady_clock::now();
     const int T = std::min(p->cfg.threads, p->cfg.games);
+    p->error.clear();
     const int64_t target = p->evals.load() + min_evals;
     std::vector<std::thread> th;
     for (int t = 0; t < T; ++t) {

@@ -560,6 +560,21 @@ def test_selfplay_pool_feeds_engine(leaves):
 
 
 @pytest.mark.gpu
+def test_pool_survives_a_failed_engine_call():
+    """An engine without weights fails the pool's first batch; the virtual visits of that batch are taken
+    back, so that the same pool plays normally once weights are loaded."""
+    from kami_amd import search as S
+    F, C, R = 30, 32, 1
+    nn = NN(8, 8, F, 4672, filters=C, residuals=R, dtype="bf16", value_mode=L.KH_VALUE_PER_SAMPLE0)
+    pool = S.Pool(nn, games=16, threads=2, nodes=16, leaves_per_tree=2, seed=4)
+    with pytest.raises(RuntimeError, match="kh_load_weights"):
+        pool.run(min_evals=100, max_seconds=10.0)
+    nn.load_weights(W.random_weights(F, C, R, seed=6, peaky=5.0), 1)
+    st = pool.run(min_evals=2000, max_seconds=30.0)
+    assert st.evals >= 2000 and st.moves > 0
+
+
+@pytest.mark.gpu
 def test_pool_priors_are_the_reference_expansion():
     """One position: the priors the pool's evaluator call returns (kh_encode_infer_legal on Env::record +
     Env::actions) equal policy[a] / sum over legal a of the full policy row (mcts.h:273-276)."""
