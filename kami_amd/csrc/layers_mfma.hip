@@ -15,8 +15,6 @@
 // B fragments from LDS, A fragments (pre-packed weights) straight from global memory / L2.
 #include "kh_internal.h"
 
-#include <type_traits>
-
 namespace kh {
 namespace lay {
 
@@ -73,18 +71,6 @@ __global__ __launch_bounds__(256) void planes_to_act_kernel(const float* __restr
     }
 }
 
-#ifdef KAMI_WIDE_DIAG
-// diagnostic build only (tools/wide_stamps.py): where a workgroup of the 3x3 skip layer spends its time
-__device__ unsigned long long g_wide_stamps[4096 * 8];
-#define WIDE_STAMP(k) do { if (TAPS == 9 && EPI == 1 && tid == 0 && blockIdx.x + gridDim.x * blockIdx.y < 2048) \
-    g_wide_stamps[(blockIdx.x + gridDim.x * blockIdx.y) * 8 + (k)] = (k) == 7 ? (unsigned long long)__builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11)) : __builtin_amdgcn_s_memtime(); } while (0)
-#define P_STAMP(it, k) do { if (EPI == 1 && lane == 0 && (it) - i0 < 4 && blockIdx.x < 256) \
-    g_wide_stamps[((blockIdx.x * 4 + ((it) - i0)) * 4 + wave) * 8 + (k)] = __builtin_amdgcn_s_memtime(); } while (0)
-#else
-#define WIDE_STAMP(k) do {} while (0)
-#define P_STAMP(it, k) do {} while (0)
-#endif
-
 struct ConvArgs {
     const unsigned short* in;     // T [B][64][Ci]
     const unsigned short* w;      // packed fragments [Co/64][taps][Ci/16][2][64 lanes][8]
@@ -137,27 +123,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     constexpr int NCH = TAPS * CPT;
     const char* stream = reinterpret_cast<const char*>(a.w) + (size_t)cb * NCH * CHUNKB;
     char* img = smem + LDS_IMG;
-    WIDE_STAMP(0);
-    WIDE_STAMP(7);
 
     // weight stream first: the ring fills while the boards are staged
 #pragma unroll
     for (int i = 0; i < RD - 1; ++i) ring_issue(stream, NCH, i, wave, lane);
-
-    // ---- this wave: board wave>>1, rows 4*(wave&1)..+3, all 64 channels of block cb
-    const int wb = wave >> 1;
-    // The skip operand (EPI 1) is requested NOW, ahead of the image loads, and rides through the loop in 16
-    // registers: fetched in the epilogue its whole memory latency was exposed (one workgroup per CU).
-    u32x4 skipv[4];
-    if (EPI == 1) {
-#pragma unroll
-        for (int it = 0; it < 4; ++it) {
-            const int lp2 = PIXMAP[(lane >> 3) + 8 * it];
-            const int pix = (4 * (wave & 1) + (lp2 >> 3)) * 8 + (lp2 & 7);
-            skipv[it] = u32x4{ 0, 0, 0, 0 };
-            if (b0 + wb < a.B) skipv[it] = *reinterpret_cast<const u32x4*>(a.skip + ((size_t)(b0 + wb) * 64 + pix) * Co + cb * 64 + (lane & 7) * 8);
-        }
-    }
 
     // ---- stage the two boards' input in LDS
     if (TAPS == 9) {
@@ -214,6 +183,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         }
     }
 
+    // ---- this wave: board wave>>1, rows 4*(wave&1)..+3, all 64 channels of block cb
+    const int wb = wave >> 1;
     const int lp = PIXMAP[lane & 31];
     const int py = 4 * (wave & 1) + (lp >> 3), px = lp & 7;
     const unsigned b_base = LDS_IMG + wb * board_bytes + ((TAPS == 9) ? (py * PITCH + px) : (py * 8 + px)) * stride + h * 16;
@@ -231,9 +202,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         return ((TAPS == 9) ? (unsigned)(((tap / 3) * PITCH + (tap % 3)) * stride) : 0u) + q * 128;
     };
     // image staged + chunk 0 landed, for everybody
-    WIDE_STAMP(1);
     asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(2 * (RD - 2)) : "memory");
-    WIDE_STAMP(2);
     V A[2][8], Bq[2][4];
 #pragma unroll
     for (int f = 0; f < 8; ++f) A[0][f] = *reinterpret_cast<const V*>(smem + lane * 16 + f * 1024);
@@ -266,9 +235,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
         }
     }
-    WIDE_STAMP(3);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // drain the ring (tail re-fetches) before exit
-    WIDE_STAMP(4);
 
     // ---- epilogue
     const int b = b0 + wb;
@@ -315,7 +282,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         float v[8] = { lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w };
         const size_t o = ((size_t)b * 64 + pix) * Co + cb * 64 + c8;
         if (EPI == 1) {
-            const u32x4 sk = skipv[it];
+            const u32x4 sk = *reinterpret_cast<const u32x4*>(a.skip + o);
             const unsigned w4[4] = { sk.x, sk.y, sk.z, sk.w };
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
@@ -330,216 +297,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         out.w = to_bits<T>(v[6]) | ((unsigned)to_bits<T>(v[7]) << 16);
         *reinterpret_cast<u32x4*>(reinterpret_cast<unsigned short*>(a.out) + o) = out;
     }
-    WIDE_STAMP(5);
-}
-
-// ---------------------------------------------------------------------------------------------
-// 3x3 layers with 128 input channels (BASELINE config 3, 10x128): PERSISTENT workgroups.  Stamps of the
-// kernel above (tools/wide_stamps.py) put 42 % of a workgroup's 8 us into staging its two boards (one
-// workgroup per CU, so the memory latency is all exposed), 33 % into the MFMA loop, 14 % into the
-// epilogue.  Here a workgroup walks through a contiguous range of (board pair, 64-channel block) items:
-//   * two image buffers (2 x 65 280 B + the 32 KB ring = 163 328 B of the 160 KB): while the items of one
-//     pair are computed, the NEXT pair's image lands in the other buffer by LDS-DMA, one pixel (256 B =
-//     64 lanes x 4 B) per global_load_lds_dword, issued a few per step;
-//   * the DMA work is split by wave, because loads complete in order per wave: waves 0-1 feed the weight
-//     ring (their vmcnt waits see only short L2 latencies), waves 2-3 the image (HBM / MALL latency, waited
-//     for once per pair);
-//   * the weight stream is cyclic over the layer's blocks and never restarts between items;
-//   * both blocks' BatchNorm shifts stay in registers.
-// The epilogue stores straight from the accumulators (the transpose tiles of the kernel above would need
-// a dead image).
-constexpr int P_NCH = 18, P_STRIDE = 128 * 2 + 16, P_BOARD = NPIX * P_STRIDE, P_IMGB = 2 * P_BOARD, P_IMG0 = RD * CHUNKB;
-constexpr int P_LDS = P_IMG0 + 2 * P_IMGB;
-static_assert(P_LDS <= 160 * 1024, "two images + ring must fit the LDS");
-
-// waves 0-1: 4 KB each of an 8 KB chunk
-__device__ __forceinline__ void p_ring_issue(const char* src, unsigned dst, int lane)
-{
-    const unsigned voff = lane * 16;
-    unsigned keep;
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\t"
-                 "global_load_lds_dwordx4 %1, %2\n\tglobal_load_lds_dwordx4 %1, %2 offset:1024\n\t"
-                 "global_load_lds_dwordx4 %1, %2 offset:2048\n\tglobal_load_lds_dwordx4 %1, %2 offset:3072\n\t"
-                 "s_mov_b32 m0, %0"
-                 : "=&s"(keep) : "v"(voff), "s"(src), "s"(dst) : "memory");
-}
-// one pixel: 128 channels = 256 bytes
-__device__ __forceinline__ void p_pixel_issue(const char* src, unsigned dst, int lane)
-{
-    const unsigned voff = lane * 4;
-    unsigned keep;
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dword %1, %2\n\ts_mov_b32 m0, %0"
-                 : "=&s"(keep) : "v"(voff), "s"(src), "s"(dst) : "memory");
-}
-// pixels [q0, q0 + n) of the 128 of a board pair into image `sel`
-__device__ __forceinline__ void p_stage(const unsigned short* in, int B, int pair, int sel, int q0, int n, int lane)
-{
-    for (int q = q0; q < q0 + n; ++q) {
-        const int bb = q >> 6, p = q & 63, b = 2 * pair + bb;
-        if (b >= B) continue;
-        const unsigned dst = (unsigned)(P_IMG0 + sel * P_IMGB + bb * P_BOARD + (((p >> 3) + 1) * PITCH + (p & 7) + 1) * P_STRIDE);
-        p_pixel_issue(reinterpret_cast<const char*>(in + ((size_t)b * 64 + p) * 128), dst, lane);
-    }
-}
-
-template <typename T, int EPI>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void conv3_c128_kernel(ConvArgs a, int items, int ncb)
-{
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    using V = typename Elem<T>::vec8;
-    const int tid = threadIdx.x, lane = tid & 63, h = lane >> 5;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const bool ring_wave = wave < 2;
-    const int G = gridDim.x, wg = blockIdx.x;
-    const int i0 = (int)((long)items * wg / G), i1 = (int)((long)items * (wg + 1) / G);
-    if (i0 >= i1) return;
-    const int Co = a.Co;
-
-    // both blocks' shifts (ncb <= 2)
-    float4 shiftv[2][2][4];
-#pragma unroll
-    for (int c = 0; c < 2; ++c)
-#pragma unroll
-        for (int ms = 0; ms < 2; ++ms)
-#pragma unroll
-            for (int g = 0; g < 4; ++g)
-                shiftv[c][ms][g] = *reinterpret_cast<const float4*>(a.shift + (c < ncb ? c : 0) * 64 + ms * 32 + 8 * g + 4 * h);
-
-    // zero the halo pixels of both images once (the DMA only ever writes interior pixels)
-    {
-        const u32x4 z = { 0, 0, 0, 0 };
-        for (int i = tid; i < 4 * NPIX; i += 256) {
-            const int pp = i % NPIX, yy = pp / PITCH, xx = pp % PITCH;
-            if (yy >= 1 && yy <= 8 && xx >= 1 && xx <= 8) continue;
-            char* d = smem + P_IMG0 + (i / NPIX) * P_BOARD + pp * P_STRIDE;
-#pragma unroll
-            for (int k = 0; k < P_STRIDE / 16; ++k) *reinterpret_cast<u32x4*>(d + k * 16) = z;
-        }
-    }
-
-    // weight stream: cyclic over the layer's ncb * 18 chunks, starting at the first item's block
-    const char* wbase = reinterpret_cast<const char*>(a.w);
-    const int wtotal = ncb * P_NCH;
-    int wc = (i0 % ncb) * P_NCH;
-    auto ring_next = [&](int slot) {
-        if (ring_wave) p_ring_issue(wbase + (size_t)wc * CHUNKB + wave * 4096, (unsigned)(slot * CHUNKB + wave * 4096), lane);
-        wc = wc + 1 == wtotal ? 0 : wc + 1;
-    };
-#pragma unroll
-    for (int i = 0; i < RD - 1; ++i) ring_next(i);
-    int sel = 0;
-    P_STAMP(i0, 6);
-    p_stage(a.in, a.B, i0 / ncb, sel, wave * 32, 32, lane);
-    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-    P_STAMP(i0, 7);
-
-    const int wb = wave >> 1;
-    const int lp = PIXMAP[lane & 31];
-    const int py = 4 * (wave & 1) + (lp >> 3), px = lp & 7;
-    const unsigned b_pix = wb * P_BOARD + (py * PITCH + px) * P_STRIDE + h * 16;
-    auto chunk_off = [](int n) -> unsigned {
-        const int tap = n / 2, q = n - tap * 2;
-        return (unsigned)(((tap / 3) * PITCH + (tap % 3)) * P_STRIDE) + q * 128;
-    };
-
-    // one item = 18 chunk steps; PAR = parity of the item's index in this workgroup (18 % 4 == 2: the ring
-    // slot of a step alternates with it)
-    auto run_item = [&](auto par_tag, int item) {
-        constexpr int PAR = decltype(par_tag)::value;
-        const int pair = item / ncb, cb = item - pair * ncb;
-        const int nitem = item + 1 < i1 ? item + 1 : -1;
-        const bool prefetch = nitem >= 0 && nitem / ncb != pair;
-        const unsigned b_base = P_IMG0 + sel * P_IMGB + b_pix;
-        P_STAMP(item, 0);
-        f32x16 acc[2];
-#pragma unroll
-        for (int ms = 0; ms < 2; ++ms)
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const float4 s = cb ? shiftv[1][ms][g] : shiftv[0][ms][g];
-                acc[ms][4 * g + 0] = s.x; acc[ms][4 * g + 1] = s.y; acc[ms][4 * g + 2] = s.z; acc[ms][4 * g + 3] = s.w;
-            }
-        // image complete (the loader waves waited for it before the previous item's last barrier, or at the
-        // start) + chunk 0 of this item landed, for everybody
-        if (ring_wave) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 * (RD - 2)) : "memory");
-        P_STAMP(item, 1);
-        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-        P_STAMP(item, 2);
-        V A[2][8], Bq[2][4];
-        {
-            const unsigned a_off = (unsigned)(((2 * PAR) % RD) * CHUNKB) + lane * 16;
-#pragma unroll
-            for (int f = 0; f < 8; ++f) A[0][f] = *reinterpret_cast<const V*>(smem + a_off + f * 1024);
-#pragma unroll
-            for (int k = 0; k < 4; ++k) Bq[0][k] = *reinterpret_cast<const V*>(smem + b_base + chunk_off(0) + k * 32);
-        }
-#pragma unroll
-        for (int n = 0; n < P_NCH; ++n) {
-            const int cur = n & 1, nxt = cur ^ 1;
-            if (ring_wave) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 * (RD - 3)) : "memory");
-            asm volatile("s_barrier" ::: "memory");
-            __builtin_amdgcn_sched_barrier(0);
-            ring_next((n + RD - 1 + 2 * PAR) % RD);
-            if (!ring_wave && prefetch && n < 16) p_stage(a.in, a.B, nitem / ncb, sel ^ 1, (wave - 2) * 64 + n * 4, 4, lane);
-            const unsigned a_off = (unsigned)(((n + 1 + 2 * PAR) % RD) * CHUNKB) + lane * 16;
-#pragma unroll
-            for (int f = 0; f < 8; ++f) A[nxt][f] = *reinterpret_cast<const V*>(smem + a_off + f * 1024);
-            if (n + 1 < P_NCH) {
-#pragma unroll
-                for (int k = 0; k < 4; ++k) Bq[nxt][k] = *reinterpret_cast<const V*>(smem + b_base + chunk_off(n + 1) + k * 32);
-            }
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                acc[0] = Elem<T>::mfma(A[cur][2 * k], Bq[cur][k], acc[0]);
-                acc[1] = Elem<T>::mfma(A[cur][2 * k + 1], Bq[cur][k], acc[1]);
-            }
-#pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
-                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-            }
-        }
-        // ---- epilogue: 4 consecutive channels of one pixel per lane and (ms, g): 8-byte stores
-        P_STAMP(item, 3);
-        const int b = 2 * pair + wb;
-        if (b < a.B) {
-            const size_t o = ((size_t)b * 64 + py * 8 + px) * Co + cb * 64 + 4 * h;
-            u32x2 sk[2][4];
-            if (EPI == 1) {
-#pragma unroll
-                for (int ms = 0; ms < 2; ++ms)
-#pragma unroll
-                    for (int g = 0; g < 4; ++g) sk[ms][g] = *reinterpret_cast<const u32x2*>(a.skip + o + ms * 32 + 8 * g);
-            }
-#pragma unroll
-            for (int ms = 0; ms < 2; ++ms)
-#pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    float v[4] = { relu_keep_nan(acc[ms][4 * g]), relu_keep_nan(acc[ms][4 * g + 1]), relu_keep_nan(acc[ms][4 * g + 2]),
-                                   relu_keep_nan(acc[ms][4 * g + 3]) };
-                    if (EPI == 1) {
-                        v[0] += from_bits<T>((unsigned short)(sk[ms][g].x & 0xffff)); v[1] += from_bits<T>((unsigned short)(sk[ms][g].x >> 16));
-                        v[2] += from_bits<T>((unsigned short)(sk[ms][g].y & 0xffff)); v[3] += from_bits<T>((unsigned short)(sk[ms][g].y >> 16));
-                    }
-                    u32x2 out;
-                    out.x = to_bits<T>(v[0]) | ((unsigned)to_bits<T>(v[1]) << 16);
-                    out.y = to_bits<T>(v[2]) | ((unsigned)to_bits<T>(v[3]) << 16);
-                    *reinterpret_cast<u32x2*>(reinterpret_cast<unsigned short*>(a.out) + o + ms * 32 + 8 * g) = out;
-                }
-        }
-        P_STAMP(item, 4);
-        if (prefetch) {
-            if (!ring_wave) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the next pair's image has landed
-            sel ^= 1;
-        }
-        P_STAMP(item, 5);
-    };
-
-    for (int item = i0; item < i1; item += 2) {
-        run_item(std::integral_constant<int, 0>{}, item);
-        if (item + 1 < i1) run_item(std::integral_constant<int, 1>{}, item + 1);
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // drain the ring (it runs ahead of the last item) before exit
 }
 
 // valueconv + vbatchnorm + relu (nn.cpp:83-85) on T activations: one thread per (board, pixel)
@@ -778,26 +535,8 @@ template <typename T, int TAPS, int EPI, int CPT> static hipError_t launch_conv_
     return hipGetLastError();
 }
 
-template <typename T, int EPI> static hipError_t launch_conv3_c128(const ConvArgs& a, hipStream_t s)
-{
-    static bool attr_done = false;
-    if (!attr_done) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3_c128_kernel<T, EPI>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        if (e != hipSuccess) return e;
-        attr_done = true;
-    }
-    const int ncb = a.Co / 64, items = ((a.B + 1) / 2) * ncb;
-    const int grid = items < 256 ? items : 256;
-    hipLaunchKernelGGL((conv3_c128_kernel<T, EPI>), dim3(grid), dim3(256), P_LDS, s, a, items, ncb);
-    return hipGetLastError();
-}
-
 template <typename T, int TAPS, int EPI> static hipError_t launch_conv(const ConvArgs& a, hipStream_t s)
 {
-    if constexpr (TAPS == 9 && EPI != 2) {
-        if (a.Ci == 128 && a.Co <= 128) return launch_conv3_c128<T, EPI>(a, s);
-    }
     switch (a.Ci / 64) {                   // input channels are padded to a multiple of 64, at most 256
     case 1: return launch_conv_cpt<T, TAPS, EPI, 1>(a, s);
     case 2: return launch_conv_cpt<T, TAPS, EPI, 2>(a, s);
@@ -843,13 +582,6 @@ template <typename T> static hipError_t run(const LayersArgs& L, hipStream_t s)
 }
 
 }  // namespace lay
-
-#ifdef KAMI_WIDE_DIAG
-extern "C" int kh_debug_wide_stamps(unsigned long long* out, int n)
-{
-    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(lay::g_wide_stamps), (size_t)n * 8, 0, hipMemcpyDeviceToHost);   // n <= 4096 * 8
-}
-#endif
 
 size_t layers_lds_bytes(int Ci) { return (size_t)lay::LDS_IMG + (size_t)2 * lay::NPIX * (Ci * 2 + 16); }
 
