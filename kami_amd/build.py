@@ -29,6 +29,7 @@ if os.environ.get("KAMI_DIAG"):
     # diagnostic build: compiles the KAMI_TOWER_DBG timing / stamp variants of the tower kernel in
     # (tools/ab_bench.py, tools/stamprun.py, tools/dbgrun.py); never the shipped configuration
     EXTRA_FLAGS["tower_mfma.hip"] = EXTRA_FLAGS["tower_mfma.hip"] + ["-DKAMI_TOWER_DIAG"]
+    EXTRA_FLAGS["layers_mfma.hip"] = ["-DKAMI_WIDE_DIAG"]
 HIPCC_FLAGS = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-Wall", "-Wno-unused-result", "-Wno-pass-failed",
                "-ffp-contract=fast"]
 

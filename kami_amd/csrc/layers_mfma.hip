@@ -7,12 +7,12 @@
 // activations of two boards no longer fit LDS twice, and the weights of one layer (up to 1.2 MB)
 // are better read once per 64-channel output block than streamed through every CU: so this
 // path is a plain per-layer implicit GEMM.  It covers BASELINE configs 3 and 5 (10x128, 20x256)
-// for parity; it has not been tuned against the roofline yet.
+// (0.23 / 0.30 of the bf16 roofline: DESIGN.md 5.3 has the in-kernel anatomy and what was tried).
 //
 // Kernel: workgroup = 2 boards x 64 output channels.  The two boards' input images (all Ci
 // channels, zero halo, pixel stride 2*Ci + 16 bytes, row pitch 12: same conflict-free geometry as
 // the tower kernel) are staged in LDS once; each of the 4 waves computes 64 channels x 32 pixels,
-// B fragments from LDS, A fragments (pre-packed weights) straight from global memory / L2.
+// B fragments from LDS, A fragments (pre-packed weights) through a 4-slot LDS ring fed by LDS-DMA.
 #include "kh_internal.h"
 
 namespace kh {
@@ -71,6 +71,15 @@ __global__ __launch_bounds__(256) void planes_to_act_kernel(const float* __restr
     }
 }
 
+#ifdef KAMI_WIDE_DIAG
+// diagnostic build only (tools/wide_stamps.py): where a workgroup of the 3x3 skip layer spends its time
+__device__ unsigned long long g_wide_stamps[2048 * 8];
+#define WIDE_STAMP(k) do { if (TAPS == 9 && EPI == 1 && tid == 0 && blockIdx.x + gridDim.x * blockIdx.y < 2048) \
+    g_wide_stamps[(blockIdx.x + gridDim.x * blockIdx.y) * 8 + (k)] = (k) == 7 ? (unsigned long long)__builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11)) : __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define WIDE_STAMP(k) do {} while (0)
+#endif
+
 struct ConvArgs {
     const unsigned short* in;     // T [B][64][Ci]
     const unsigned short* w;      // packed fragments [Co/64][taps][Ci/16][2][64 lanes][8]
@@ -88,11 +97,12 @@ constexpr int RD = 4;
 constexpr int CHUNKB = 8192;
 constexpr int LDS_IMG = RD * CHUNKB;
 
+template <int RDN = RD>
 __device__ __forceinline__ void ring_issue(const char* stream, int nch, int c, int wave, int lane)
 {
     const int cs = c < nch ? c : nch - 1;                  // past the end: re-fetch the last chunk into a
     const char* sbase = stream + (size_t)cs * CHUNKB + wave * 2048;   // free slot (keeps the vmcnt count constant)
-    const unsigned dst = (unsigned)((c % RD) * CHUNKB + wave * 2048);
+    const unsigned dst = (unsigned)((c % RDN) * CHUNKB + wave * 2048);
     const unsigned voff = lane * 16;
     unsigned keep;
     asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\t"
@@ -107,9 +117,16 @@ __device__ __forceinline__ void ring_issue(const char* stream, int nch, int c, i
 // run-time loop hipcc rotated the double buffer through v_mov copies and issued the next chunk's
 // activation reads (behind a run-time address computation) at the END of a step, exposing their
 // latency after every barrier: 2.6x the tower's time per step.
-template <typename T, int TAPS, int EPI, int CPT>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void conv_mfma_kernel(ConvArgs a)
+// RDN = ring slots.  RDN == 2 (3x3 layers with 128 input channels): ring + image = 81 664 B, so TWO workgroups
+// share a CU (256 registers each) and one's staging / epilogue runs under the other's MFMAs — with one
+// workgroup per CU all CUs stage at the same moment (42 % of a workgroup's time at 128 channels,
+// tools/wide_stamps.py) and then leave the memory system idle.  A 2-slot ring refills the slot of the chunk
+// that is already in registers (AHEAD), so its reads must have completed before the step's barrier.
+template <typename T, int TAPS, int EPI, int CPT, int RDN = RD>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, RDN == 2 ? 2 : 1))) void conv_mfma_kernel(ConvArgs a)
 {
+    constexpr int AHEAD = RDN == 2 ? 1 : 0;
+    constexpr int LDS_IMG = RDN * CHUNKB;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     using V = typename Elem<T>::vec8;
     const int tid = threadIdx.x, lane = tid & 63, h = lane >> 5;
@@ -123,10 +140,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     constexpr int NCH = TAPS * CPT;
     const char* stream = reinterpret_cast<const char*>(a.w) + (size_t)cb * NCH * CHUNKB;
     char* img = smem + LDS_IMG;
+    WIDE_STAMP(0);
+    WIDE_STAMP(7);
 
     // weight stream first: the ring fills while the boards are staged
 #pragma unroll
-    for (int i = 0; i < RD - 1; ++i) ring_issue(stream, NCH, i, wave, lane);
+    for (int i = 0; i < RDN - 1 + AHEAD; ++i) ring_issue<RDN>(stream, NCH, i, wave, lane);
 
     // ---- stage the two boards' input in LDS
     if (TAPS == 9) {
@@ -202,7 +221,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         return ((TAPS == 9) ? (unsigned)(((tap / 3) * PITCH + (tap % 3)) * stride) : 0u) + q * 128;
     };
     // image staged + chunk 0 landed, for everybody
-    asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(2 * (RD - 2)) : "memory");
+    WIDE_STAMP(1);
+    asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(2 * (RDN - 2 + AHEAD)) : "memory");
+    WIDE_STAMP(2);
     V A[2][8], Bq[2][4];
 #pragma unroll
     for (int f = 0; f < 8; ++f) A[0][f] = *reinterpret_cast<const V*>(smem + lane * 16 + f * 1024);
@@ -214,10 +235,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 #pragma unroll
     for (int n = 0; n < NCH; ++n) {
         const int cur = n & 1, nxt = cur ^ 1;
-        asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(2 * (RD - 3)) : "memory");
+        if (AHEAD) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(2 * (RDN - 3 + AHEAD)) : "memory");
+        else asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(2 * (RDN - 3 + AHEAD)) : "memory");
         __builtin_amdgcn_sched_barrier(0);
-        ring_issue(stream, NCH, n + RD - 1, wave, lane);
-        const unsigned a_off = (unsigned)(((n + 1) % RD) * CHUNKB) + lane * 16;
+        ring_issue<RDN>(stream, NCH, n + RDN - 1 + AHEAD, wave, lane);
+        const unsigned a_off = (unsigned)(((n + 1) % RDN) * CHUNKB) + lane * 16;
 #pragma unroll
         for (int f = 0; f < 8; ++f) A[nxt][f] = *reinterpret_cast<const V*>(smem + a_off + f * 1024);
         if (n + 1 < NCH) {
@@ -235,7 +257,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
         }
     }
+    WIDE_STAMP(3);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // drain the ring (tail re-fetches) before exit
+    WIDE_STAMP(4);
 
     // ---- epilogue
     const int b = b0 + wb;
@@ -297,6 +321,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         out.w = to_bits<T>(v[6]) | ((unsigned)to_bits<T>(v[7]) << 16);
         *reinterpret_cast<u32x4*>(reinterpret_cast<unsigned short*>(a.out) + o) = out;
     }
+    WIDE_STAMP(5);
 }
 
 // valueconv + vbatchnorm + relu (nn.cpp:83-85) on T activations: one thread per (board, pixel)
@@ -519,20 +544,31 @@ static hipError_t run_f32(const LayersArgs& L, hipStream_t s)
     return hipGetLastError();
 }
 
-template <typename T, int TAPS, int EPI, int CPT> static hipError_t launch_conv_cpt(const ConvArgs& a, hipStream_t s)
+template <typename T, int TAPS, int EPI, int CPT, int RDN> static hipError_t launch_conv_rd(const ConvArgs& a, hipStream_t s)
 {
     const int stride = a.Ci * 2 + 16;
     const int image = 2 * ((TAPS == 9) ? NPIX : 64) * stride, tiles = 4 * 32 * (64 * 4 + 16);   // the epilogue's transpose tiles reuse the image
-    const int lds = LDS_IMG + (image > tiles ? image : tiles);
+    const int lds = RDN * CHUNKB + (image > tiles ? image : tiles);
     static bool attr_done = false;
     if (!attr_done) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_mfma_kernel<T, TAPS, EPI, CPT>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_mfma_kernel<T, TAPS, EPI, CPT, RDN>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) return e;
         attr_done = true;
     }
-    hipLaunchKernelGGL((conv_mfma_kernel<T, TAPS, EPI, CPT>), dim3((a.B + 1) / 2, a.Co / 64), dim3(256), lds, s, a);
+    hipLaunchKernelGGL((conv_mfma_kernel<T, TAPS, EPI, CPT, RDN>), dim3((a.B + 1) / 2, a.Co / 64), dim3(256), lds, s, a);
     return hipGetLastError();
+}
+
+template <typename T, int TAPS, int EPI, int CPT> static hipError_t launch_conv_cpt(const ConvArgs& a, hipStream_t s)
+{
+    // 128-channel 3x3 layers with more workgroups than CUs: the 2-slot ring variant, two workgroups per CU
+    // (10x128 at batch 1024: 726 -> 632 us per forward; with one workgroup per CU anyway it only costs:
+    // 219 -> 251 us at batch 256)
+    if constexpr (TAPS == 9 && CPT == 2) {
+        if ((long)((a.B + 1) / 2) * (a.Co / 64) > 256) return launch_conv_rd<T, TAPS, EPI, CPT, 2>(a, s);
+    }
+    return launch_conv_rd<T, TAPS, EPI, CPT, RD>(a, s);
 }
 
 template <typename T, int TAPS, int EPI> static hipError_t launch_conv(const ConvArgs& a, hipStream_t s)
@@ -582,6 +618,13 @@ template <typename T> static hipError_t run(const LayersArgs& L, hipStream_t s)
 }
 
 }  // namespace lay
+
+#ifdef KAMI_WIDE_DIAG
+extern "C" int kh_debug_wide_stamps(unsigned long long* out, int n)
+{
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(lay::g_wide_stamps), (size_t)n * 8, 0, hipMemcpyDeviceToHost);
+}
+#endif
 
 size_t layers_lds_bytes(int Ci) { return (size_t)lay::LDS_IMG + (size_t)2 * lay::NPIX * (Ci * 2 + 16); }
 
