@@ -189,23 +189,27 @@ void pack_layer(std::vector<uint16_t>& out, int dtype, const float* w, const flo
     while (out.size() % 4096) out.push_back(0);
 }
 
-// Fragments of one layer for layers_mfma.hip: [Co/64][tap][Ci/16][2][lane][8], BN scale folded in.
+// Fragments of one layer for layers_mfma.hip: [Co/64][tap][Ci/16][2][lane][8], BN scale folded in.  3x3 layers
+// with 256 (padded) input channels are laid out as two passes of 128 channels, [Co/64][pass][tap][8][2][lane][8]:
+// the kernel's two-pass variant stages half an image at a time (layers_mfma.hip).
 void pack_layer_generic(std::vector<uint16_t>& out, int dtype, const float* w, const float* scale,
                         int Co, int Ci, int taps, int CoP, int CiP)
 {
+    const int npass = (taps == 9 && CiP == 256) ? 2 : 1, kpp = CiP / 16 / npass;
     for (int cb = 0; cb < CoP / 64; ++cb)
-        for (int tap = 0; tap < taps; ++tap)
-            for (int ks = 0; ks < CiP / 16; ++ks)
-                for (int ms = 0; ms < 2; ++ms)
-                    for (int l = 0; l < 64; ++l) {
-                        const int r = l & 31, h = l >> 5;
-                        for (int j = 0; j < 8; ++j) {
-                            const int co = cb * 64 + ms * 32 + r, ci = ks * 16 + 8 * h + j;
-                            float v = 0.0f;
-                            if (co < Co && ci < Ci) v = w[((size_t)co * Ci + ci) * taps + tap] * (scale ? scale[co] : 1.0f);
-                            out.push_back(dtype == KH_BF16 ? f2bf16(v) : f2f16(v));
+        for (int pass = 0; pass < npass; ++pass)
+            for (int tap = 0; tap < taps; ++tap)
+                for (int kk = 0; kk < kpp; ++kk)
+                    for (int ms = 0; ms < 2; ++ms)
+                        for (int l = 0; l < 64; ++l) {
+                            const int r = l & 31, h = l >> 5, ks = pass * kpp + kk;
+                            for (int j = 0; j < 8; ++j) {
+                                const int co = cb * 64 + ms * 32 + r, ci = ks * 16 + 8 * h + j;
+                                float v = 0.0f;
+                                if (co < Co && ci < Ci) v = w[((size_t)co * Ci + ci) * taps + tap] * (scale ? scale[co] : 1.0f);
+                                out.push_back(dtype == KH_BF16 ? f2bf16(v) : f2f16(v));
+                            }
                         }
-                    }
 }
 
 // fp32 fragments for conv_f32_kernel: [Co/64][tap][Ci/8][2][lane][4]; lane (r, h) holds

@@ -122,7 +122,10 @@ __device__ __forceinline__ void ring_issue(const char* stream, int nch, int c, i
 // workgroup per CU all CUs stage at the same moment (42 % of a workgroup's time at 128 channels,
 // tools/wide_stamps.py) and then leave the memory system idle.  A 2-slot ring refills the slot of the chunk
 // that is already in registers (AHEAD), so its reads must have completed before the step's barrier.
-template <typename T, int TAPS, int EPI, int CPT, int RDN = RD>
+// NP = passes over the input channels, CPT * 64 of them each (256 channels as 2 x 128: the image of one pass is
+// half the size, so that the two-workgroup variant exists there too; the 256-channel weights are packed
+// pass-major for every variant, see chunk_off).
+template <typename T, int TAPS, int EPI, int CPT, int RDN = RD, int NP = 1>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, RDN == 2 ? 2 : 1))) void conv_mfma_kernel(ConvArgs a)
 {
     constexpr int AHEAD = RDN == 2 ? 1 : 0;
@@ -131,23 +134,24 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, RDN == 2
     using V = typename Elem<T>::vec8;
     const int tid = threadIdx.x, lane = tid & 63, h = lane >> 5;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    constexpr int Ci = CPT * 64;                           // a chunk never straddles taps
+    constexpr int Ci = CPT * 64;                           // channels of one pass; a chunk never straddles taps
+    constexpr int CiTot = NP * Ci;
     const int Co = a.Co;
     constexpr int stride = Ci * 2 + 16;
     constexpr int npx = (TAPS == 9) ? NPIX : 64;          // pixels per board image
     constexpr int board_bytes = npx * stride;
     const int b0 = blockIdx.x * 2, cb = blockIdx.y;
-    constexpr int NCH = TAPS * CPT;
-    const char* stream = reinterpret_cast<const char*>(a.w) + (size_t)cb * NCH * CHUNKB;
+    constexpr int NCH = TAPS * CPT, NCHT = NP * NCH;
+    const char* stream = reinterpret_cast<const char*>(a.w) + (size_t)cb * NCHT * CHUNKB;
     char* img = smem + LDS_IMG;
     WIDE_STAMP(0);
     WIDE_STAMP(7);
 
     // weight stream first: the ring fills while the boards are staged
 #pragma unroll
-    for (int i = 0; i < RDN - 1 + AHEAD; ++i) ring_issue<RDN>(stream, NCH, i, wave, lane);
+    for (int i = 0; i < RDN - 1 + AHEAD; ++i) ring_issue<RDN>(stream, NCHT, i, wave, lane);
 
-    // ---- stage the two boards' input in LDS
+    // ---- zero halo of the two boards' images (staging only ever writes interior pixels)
     if (TAPS == 9) {
         const u32x4 z = { 0, 0, 0, 0 };
         constexpr int per_px = stride / 16;
@@ -158,12 +162,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, RDN == 2
             for (int k = 0; k < per_px; ++k) *reinterpret_cast<u32x4*>(d + k * 16) = z;
         }
     }
-    {
+    // ---- stage the two boards' input channels [pass * Ci, (pass + 1) * Ci) in LDS
+    auto stage = [&](int pass) {
         // A thread owns 4 loads of 16 bytes per 64 input channels.  Up to 128 channels: batches of four in
         // flight, then their LDS writes; from 192 channels: all of them at once (one exposed memory
         // latency for the whole image).  Measured on one device: all 16 at once is +5 % end to end at
         // 256 channels, all 8 at once -22 % at 128 channels.
         constexpr int CH = Ci / 8;
+        const unsigned short* src = a.in + pass * Ci;
         if (CPT >= 3) {
             constexpr int NL = 2 * 64 * CH / 256;
             u32x4 v[NL];
@@ -172,7 +178,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, RDN == 2
                 const int i = tid + u * 256;
                 const int bb = i / (64 * CH), p = (i / CH) & 63, c = i % CH;
                 v[u] = u32x4{ 0, 0, 0, 0 };
-                if (b0 + bb < a.B) v[u] = *reinterpret_cast<const u32x4*>(a.in + ((size_t)(b0 + bb) * 64 + p) * Ci + c * 8);
+                if (b0 + bb < a.B) v[u] = *reinterpret_cast<const u32x4*>(src + ((size_t)(b0 + bb) * 64 + p) * CiTot + c * 8);
             }
 #pragma unroll
             for (int u = 0; u < NL; ++u) {
@@ -189,7 +195,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, RDN == 2
                     const int i = i0 + u * 256;
                     const int bb = i / (64 * CH), p = (i / CH) & 63, c = i % CH;
                     v[u] = u32x4{ 0, 0, 0, 0 };
-                    if (b0 + bb < a.B) v[u] = *reinterpret_cast<const u32x4*>(a.in + ((size_t)(b0 + bb) * 64 + p) * Ci + c * 8);
+                    if (b0 + bb < a.B) v[u] = *reinterpret_cast<const u32x4*>(src + ((size_t)(b0 + bb) * 64 + p) * CiTot + c * 8);
                 }
 #pragma unroll
                 for (int u = 0; u < 4; ++u) {
@@ -200,7 +206,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, RDN == 2
                 }
             }
         }
-    }
+    };
 
     // ---- this wave: board wave>>1, rows 4*(wave&1)..+3, all 64 channels of block cb
     const int wb = wave >> 1;
@@ -215,46 +221,56 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, RDN == 2
             const float4 s = *reinterpret_cast<const float4*>(a.shift + cb * 64 + ms * 32 + 8 * g + 4 * h);
             acc[ms][4 * g + 0] = s.x; acc[ms][4 * g + 1] = s.y; acc[ms][4 * g + 2] = s.z; acc[ms][4 * g + 3] = s.w;
         }
-    // byte offset of the first k-step of chunk n in the image, relative to b_base (a constant after unrolling)
+    // byte offset of the first k-step of chunk n (of a pass) in the image, relative to b_base (a constant after
+    // unrolling).  Chunks are tap-major, 64 channels each — except 256-channel 3x3 layers, which are packed as
+    // two 128-channel passes (kh_api.hip: pack_layer_generic): the one-pass variant walks that order too.
     auto chunk_off = [](int n) -> unsigned {
-        const int tap = n / CPT, q = n - tap * CPT;
+        int tap = n / CPT, q = n - tap * CPT;
+        if (TAPS == 9 && CPT == 4 && NP == 1) { tap = (n % 18) / 2; q = (n / 18) * 2 + (n & 1); }
         return ((TAPS == 9) ? (unsigned)(((tap / 3) * PITCH + (tap % 3)) * stride) : 0u) + q * 128;
     };
-    // image staged + chunk 0 landed, for everybody
-    WIDE_STAMP(1);
-    asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(2 * (RDN - 2 + AHEAD)) : "memory");
-    WIDE_STAMP(2);
     V A[2][8], Bq[2][4];
 #pragma unroll
-    for (int f = 0; f < 8; ++f) A[0][f] = *reinterpret_cast<const V*>(smem + lane * 16 + f * 1024);
+    for (int pass = 0; pass < NP; ++pass) {
+        if (pass > 0) __syncthreads();                     // everybody is done reading the previous pass's image
+        stage(pass);
+        // image staged + first chunk of the pass landed, for everybody
+        if (pass == 0) WIDE_STAMP(1);
+        asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(2 * (RDN - 2 + AHEAD)) : "memory");
+        if (pass == 0) WIDE_STAMP(2);
+        {
+            const unsigned a_off = (unsigned)(((pass * NCH) % RDN) * CHUNKB) + lane * 16;
 #pragma unroll
-    for (int k = 0; k < 4; ++k) Bq[0][k] = *reinterpret_cast<const V*>(smem + b_base + chunk_off(0) + k * 32);
-
-    // one chunk step per iteration, fully unrolled: register set n & 1 holds chunk n (see tower_mfma.hip
-    // for the ring protocol and the pinned read / MFMA interleave)
+            for (int f = 0; f < 8; ++f) A[0][f] = *reinterpret_cast<const V*>(smem + a_off + f * 1024);
 #pragma unroll
-    for (int n = 0; n < NCH; ++n) {
-        const int cur = n & 1, nxt = cur ^ 1;
-        if (AHEAD) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(2 * (RDN - 3 + AHEAD)) : "memory");
-        else asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(2 * (RDN - 3 + AHEAD)) : "memory");
-        __builtin_amdgcn_sched_barrier(0);
-        ring_issue<RDN>(stream, NCH, n + RDN - 1 + AHEAD, wave, lane);
-        const unsigned a_off = (unsigned)(((n + 1) % RDN) * CHUNKB) + lane * 16;
-#pragma unroll
-        for (int f = 0; f < 8; ++f) A[nxt][f] = *reinterpret_cast<const V*>(smem + a_off + f * 1024);
-        if (n + 1 < NCH) {
-#pragma unroll
-            for (int k = 0; k < 4; ++k) Bq[nxt][k] = *reinterpret_cast<const V*>(smem + b_base + chunk_off(n + 1) + k * 32);
+            for (int k = 0; k < 4; ++k) Bq[0][k] = *reinterpret_cast<const V*>(smem + b_base + chunk_off(0) + k * 32);
         }
+        // one chunk step per iteration, fully unrolled: register set n & 1 holds chunk n (see tower_mfma.hip
+        // for the ring protocol and the pinned read / MFMA interleave)
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            acc[0] = Elem<T>::mfma(A[cur][2 * k], Bq[cur][k], acc[0]);
-            acc[1] = Elem<T>::mfma(A[cur][2 * k + 1], Bq[cur][k], acc[1]);
-        }
+        for (int n = 0; n < NCH; ++n) {
+            const int cur = n & 1, nxt = cur ^ 1, g = pass * NCH + n;
+            if (AHEAD) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(2 * (RDN - 3 + AHEAD)) : "memory");
+            else asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(2 * (RDN - 3 + AHEAD)) : "memory");
+            __builtin_amdgcn_sched_barrier(0);
+            ring_issue<RDN>(stream, NCHT, g + RDN - 1 + AHEAD, wave, lane);
+            const unsigned a_off = (unsigned)(((g + 1) % RDN) * CHUNKB) + lane * 16;
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
-            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            for (int f = 0; f < 8; ++f) A[nxt][f] = *reinterpret_cast<const V*>(smem + a_off + f * 1024);
+            if (n + 1 < NCH) {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) Bq[nxt][k] = *reinterpret_cast<const V*>(smem + b_base + chunk_off(n + 1) + k * 32);
+            }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                acc[0] = Elem<T>::mfma(A[cur][2 * k], Bq[cur][k], acc[0]);
+                acc[1] = Elem<T>::mfma(A[cur][2 * k + 1], Bq[cur][k], acc[1]);
+            }
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            }
         }
     }
     WIDE_STAMP(3);
@@ -544,29 +560,33 @@ static hipError_t run_f32(const LayersArgs& L, hipStream_t s)
     return hipGetLastError();
 }
 
-template <typename T, int TAPS, int EPI, int CPT, int RDN> static hipError_t launch_conv_rd(const ConvArgs& a, hipStream_t s)
+template <typename T, int TAPS, int EPI, int CPT, int RDN, int NP = 1> static hipError_t launch_conv_rd(const ConvArgs& a, hipStream_t s)
 {
-    const int stride = a.Ci * 2 + 16;
+    const int stride = CPT * 64 * 2 + 16;                  // image of one pass
     const int image = 2 * ((TAPS == 9) ? NPIX : 64) * stride, tiles = 4 * 32 * (64 * 4 + 16);   // the epilogue's transpose tiles reuse the image
     const int lds = RDN * CHUNKB + (image > tiles ? image : tiles);
     static bool attr_done = false;
     if (!attr_done) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_mfma_kernel<T, TAPS, EPI, CPT, RDN>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_mfma_kernel<T, TAPS, EPI, CPT, RDN, NP>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) return e;
         attr_done = true;
     }
-    hipLaunchKernelGGL((conv_mfma_kernel<T, TAPS, EPI, CPT, RDN>), dim3((a.B + 1) / 2, a.Co / 64), dim3(256), lds, s, a);
+    hipLaunchKernelGGL((conv_mfma_kernel<T, TAPS, EPI, CPT, RDN, NP>), dim3((a.B + 1) / 2, a.Co / 64), dim3(256), lds, s, a);
     return hipGetLastError();
 }
 
 template <typename T, int TAPS, int EPI, int CPT> static hipError_t launch_conv_cpt(const ConvArgs& a, hipStream_t s)
 {
-    // 128-channel 3x3 layers with more workgroups than CUs: the 2-slot ring variant, two workgroups per CU
-    // (10x128 at batch 1024: 726 -> 632 us per forward; with one workgroup per CU anyway it only costs:
-    // 219 -> 251 us at batch 256)
+    // 3x3 layers with more workgroups than CUs: the 2-slot-ring variant, two workgroups per CU (128 input
+    // channels; 256 as two passes of 128).  10x128 at batch 1024: 726 -> 600 us per forward; with one
+    // workgroup per CU anyway it only costs (219 -> 251 us at batch 256), so this is decided per launch.
+    const bool crowded = (long)((a.B + 1) / 2) * (a.Co / 64) > 256;
     if constexpr (TAPS == 9 && CPT == 2) {
-        if ((long)((a.B + 1) / 2) * (a.Co / 64) > 256) return launch_conv_rd<T, TAPS, EPI, CPT, 2>(a, s);
+        if (crowded) return launch_conv_rd<T, TAPS, EPI, 2, 2>(a, s);
+    }
+    if constexpr (TAPS == 9 && CPT == 4) {
+        if (crowded) return launch_conv_rd<T, TAPS, EPI, 2, 2, 2>(a, s);
     }
     return launch_conv_rd<T, TAPS, EPI, CPT, RD>(a, s);
 }

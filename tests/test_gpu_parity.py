@@ -181,21 +181,21 @@ def test_forward_wide_nets_vs_oracle(dtype, F, C, R, B):
 
 
 @pytest.mark.parametrize("dtype", ["bf16", "f16"])
-@pytest.mark.parametrize("B", [513, 1024])
-def test_wide_128_two_workgroups_per_cu_variant_matches(dtype, B):
-    """128-filter nets: with more workgroups than CUs the 3x3 layers run the 2-slot-ring variant (two
-    workgroups per CU).  It is the same arithmetic in the same order: the same boards evaluated 100 at a
-    time (4-slot variant, one workgroup per CU) must give the same bits."""
-    F, C, R = 119, 128, 2
+@pytest.mark.parametrize("C,B,step", [(128, 513, 100), (128, 1024, 100), (256, 200, 50), (256, 131, 50)])
+def test_wide_two_workgroups_per_cu_variant_matches(dtype, C, B, step):
+    """Wide nets: with more workgroups than CUs the 3x3 layers run the 2-slot-ring variant, two workgroups
+    per CU (256 channels: as two passes of 128).  It is the same arithmetic in the same order: the same
+    boards evaluated `step` at a time (4-slot variant, one workgroup per CU) must give the same bits."""
+    F, R = 119, 2
     nn = NN(8, 8, F, 4672, filters=C, residuals=R, dtype=dtype)
     nn.load_weights(W.random_weights(F, C, R, seed=77, peaky=10.0), 1)
     x = np.random.default_rng(B).random((B, 8, 8, F), dtype=np.float32)
     p, vf, lg = nn.infer_full(x)
-    for lo in range(0, B, 100):
-        pp, pv, pl = nn.infer_full(x[lo:lo + 100])
-        np.testing.assert_array_equal(lg[lo:lo + 100], pl)
-        np.testing.assert_array_equal(p[lo:lo + 100], pp)
-        np.testing.assert_array_equal(vf[lo:lo + 100], pv)
+    for lo in range(0, B, step):
+        pp, pv, pl = nn.infer_full(x[lo:lo + step])
+        np.testing.assert_array_equal(lg[lo:lo + step], pl)
+        np.testing.assert_array_equal(p[lo:lo + step], pp)
+        np.testing.assert_array_equal(vf[lo:lo + step], pv)
 
 
 def test_mfma_unsupported_config_fails_loudly():
