@@ -801,10 +801,24 @@ int kh_train(kh_engine* e, const float* inputs, const float* obs_p, const float*
     for (int i = 0; i < trajectories; ++i) picker[i] = i;
     auto rng = std::default_random_engine{};
     const size_t in_row = (size_t)64 * F;
-    std::vector<float> next_input((size_t)B * in_row, 0.0f), next_policy((size_t)B * KH_PSIZE, 0.0f), next_value((size_t)B, 0.0f);
-    std::vector<float> loss_rows((size_t)B * 2);
+    // batch staging in page-locked memory (rows persist from batch to batch like the reference's stack buffers)
+    PinMem pin;
+    const size_t n_in = (size_t)B * in_row, n_p = (size_t)B * KH_PSIZE;
+    if (pin.ensure((n_in + n_p + (size_t)B + (size_t)B * 2) * 4)) return KH_ERR_HIP;
+    float* next_input = reinterpret_cast<float*>(pin.p);
+    float* next_policy = next_input + n_in;
+    float* next_value = next_policy + n_p;
+    float* loss_rows = next_value + B;
+    memset(pin.p, 0, (n_in + n_p + (size_t)B + (size_t)B * 2) * 4);
     float firstloss = 0.0f, lastloss = 0.0f;
     const kh::StepBuffers sb{ params.as<float>(), grads.as<float>(), work.as<float>() };
+    // A step is ~120 small launches on fixed buffers: recorded once as a graph, replayed per batch (with the
+    // tiled conv kernels the host's launch work, not the GPU, bounded a step).  Falls back to plain launches.
+    struct GraphGuard {
+        hipGraph_t g = nullptr; hipGraphExec_t x = nullptr;
+        ~GraphGuard() { if (x) (void)hipGraphExecDestroy(x); if (g) (void)hipGraphDestroy(g); }
+    } graph;
+    bool graph_tried = false;
     for (int epoch = 0; epoch < cfg->epochs; ++epoch) {
         std::shuffle(picker.begin(), picker.end(), rng);
         float avgloss = 0.0f;
@@ -818,11 +832,23 @@ int kh_train(kh_engine* e, const float* inputs, const float* obs_p, const float*
                 next_value[i] = obs_v[src];
             }
             base += i;
-            HIPCHK(hipMemcpyAsync(dx.p, next_input.data(), next_input.size() * 4, hipMemcpyHostToDevice, st));
-            HIPCHK(hipMemcpyAsync(dp.p, next_policy.data(), next_policy.size() * 4, hipMemcpyHostToDevice, st));
-            HIPCHK(hipMemcpyAsync(dv.p, next_value.data(), next_value.size() * 4, hipMemcpyHostToDevice, st));
-            HIPCHK(kh::train_step(*net, sb, dx.as<float>(), dp.as<float>(), dv.as<float>(), B, cfg->lr, dloss.as<float>(), st));
-            HIPCHK(hipMemcpyAsync(loss_rows.data(), dloss.p, loss_rows.size() * 4, hipMemcpyDeviceToHost, st));
+            HIPCHK(hipMemcpyAsync(dx.p, next_input, n_in * 4, hipMemcpyHostToDevice, st));
+            HIPCHK(hipMemcpyAsync(dp.p, next_policy, n_p * 4, hipMemcpyHostToDevice, st));
+            HIPCHK(hipMemcpyAsync(dv.p, next_value, (size_t)B * 4, hipMemcpyHostToDevice, st));
+            if (!graph_tried) {
+                graph_tried = true;
+                if (hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal) == hipSuccess) {
+                    const hipError_t ce = kh::train_step(*net, sb, dx.as<float>(), dp.as<float>(), dv.as<float>(), B, cfg->lr, dloss.as<float>(), st);
+                    const hipError_t ee = hipStreamEndCapture(st, &graph.g);
+                    if (ce != hipSuccess || ee != hipSuccess || hipGraphInstantiate(&graph.x, graph.g, nullptr, nullptr, 0) != hipSuccess) {
+                        if (graph.x) { (void)hipGraphExecDestroy(graph.x); graph.x = nullptr; }
+                        (void)hipGetLastError();
+                    }
+                }
+            }
+            if (graph.x) HIPCHK(hipGraphLaunch(graph.x, st));
+            else HIPCHK(kh::train_step(*net, sb, dx.as<float>(), dp.as<float>(), dv.as<float>(), B, cfg->lr, dloss.as<float>(), st));
+            HIPCHK(hipMemcpyAsync(loss_rows, dloss.p, (size_t)B * 2 * 4, hipMemcpyDeviceToHost, st));
             HIPCHK(hipStreamSynchronize(st));
             float lp = 0.0f, lv = 0.0f;
             for (int b = 0; b < B; ++b) { lp += loss_rows[b]; lv += loss_rows[B + b]; }

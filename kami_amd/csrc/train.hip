@@ -24,70 +24,200 @@ namespace {
 constexpr float BN_EPS = 1e-5f, BN_MOMENTUM = 0.1f;
 
 // ---- conv ----------------------------------------------------------------------------------------
-// y[b][p][co] = bias[co] + sum_{tap,ci} x[b][p + off(tap)][ci] * w[co][ci][tap]
-__global__ __launch_bounds__(256) void conv_fwd_kernel(const float* __restrict__ w, const float* __restrict__ bias,
-                                                       const float* __restrict__ x, float* __restrict__ y,
-                                                       int B, int Ci, int Co, int T)
+// fp32 VALU kernels, tiled through LDS (the first versions — one thread per output running through global
+// memory — spent 92 % of a step in these three: strided weight gathers, one long serial chain per thread).
+//
+// forward and data gradient are the same loop with the roles swapped:
+//   forward : y[b][p][co]  = bias[co] + sum_{tap,ci} x[b][p + off(tap)][ci] * w[co][ci][tap]
+//   dgrad   : dx[b][p][ci] (+)=        sum_{tap,co} dy[b][p - off(tap)][co] * w[co][ci][tap]
+// One workgroup = one board x OB outputs (8 when the launch would otherwise leave most CUs idle, else 16): the board's input (zero halo, pixel stride K + 1 floats so
+// that the 64 pixels of a wave fall in different banks) and the outputs' weights are staged per
+// 64-channel slice of the reduction; thread = (pixel, OB / 4 outputs).
+constexpr int CV_KC = 64;
+template <int T, bool DGRAD, int CV_OB>
+__global__ __launch_bounds__(256) void conv_tiled_kernel(const float* __restrict__ w, const float* __restrict__ bias,
+                                                         const float* __restrict__ in, float* __restrict__ out,
+                                                         int Ci, int Co, int accumulate)
 {
-    const long total = (long)B * 64 * Co;
-    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
-        const int co = (int)(idx % Co), pix = (int)((idx / Co) & 63);
-        const long b = idx / ((long)Co * 64);
-        const int py = pix >> 3, px = pix & 7;
-        float acc = 0.0f;
-        for (int t = 0; t < T; ++t) {
-            const int iy = T == 9 ? py + t / 3 - 1 : py, ix = T == 9 ? px + t % 3 - 1 : px;
-            if (iy < 0 || iy > 7 || ix < 0 || ix > 7) continue;
-            const float* xi = x + (b * 64 + iy * 8 + ix) * Ci;
-            const float* wk = w + (size_t)co * Ci * T + t;
-            for (int ci = 0; ci < Ci; ++ci) acc = fmaf(xi[ci], wk[(size_t)ci * T], acc);
+    constexpr int NPX = T == 9 ? 100 : 64, KS = CV_KC + 1, CV_PT = CV_OB / 4;
+    __shared__ float in_s[NPX * KS];
+    __shared__ float w_s[CV_OB * CV_KC * T];
+    const int K = DGRAD ? Co : Ci, O = DGRAD ? Ci : Co;
+    const int tid = threadIdx.x, b = blockIdx.x, o0 = blockIdx.y * CV_OB;
+    const int p = tid & 63, og = tid >> 6, py = p >> 3, px = p & 7;
+    for (int i = tid; i < NPX * KS; i += 256) in_s[i] = 0.0f;             // the halo stays zero
+    float acc[CV_PT];
+#pragma unroll
+    for (int j = 0; j < CV_PT; ++j) acc[j] = 0.0f;
+    for (int k0 = 0; k0 < K; k0 += CV_KC) {
+        const int kn = K - k0 < CV_KC ? K - k0 : CV_KC;
+        __syncthreads();                                                   // previous slice consumed (first: zeros written)
+        for (int i = tid; i < 64 * CV_KC; i += 256) {
+            const int q = i / CV_KC, k = i % CV_KC;
+            const int pix = T == 9 ? ((q >> 3) + 1) * 10 + (q & 7) + 1 : q;
+            in_s[pix * KS + k] = k < kn ? in[((long)b * 64 + q) * K + k0 + k] : 0.0f;
         }
-        y[idx] = acc + bias[co];
+        for (int i = tid; i < CV_OB * CV_KC * T; i += 256) {
+            const int t = i % T, k = (i / T) % CV_KC, ol = i / (T * CV_KC), o = o0 + ol;
+            float v = 0.0f;
+            if (o < O && k < kn) v = DGRAD ? w[((size_t)(k0 + k) * Ci + o) * T + t] : w[((size_t)o * Ci + k0 + k) * T + t];
+            w_s[i] = v;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int t = 0; t < T; ++t) {
+            int oy = T == 9 ? t / 3 - 1 : 0, ox = T == 9 ? t % 3 - 1 : 0;
+            if (DGRAD) { oy = -oy; ox = -ox; }     // this input pixel p feeds the output pixel p - off(t)
+            const float* xi = in_s + (T == 9 ? ((py + oy + 1) * 10 + px + ox + 1) : p) * KS;
+            const float* wk = w_s + (size_t)(og * CV_PT) * CV_KC * T + t;
+            for (int k = 0; k < kn; ++k) {
+                const float xv = xi[k];
+#pragma unroll
+                for (int j = 0; j < CV_PT; ++j) acc[j] = fmaf(xv, wk[(j * CV_KC + k) * T], acc[j]);
+            }
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < CV_PT; ++j) {
+        const int o = o0 + og * CV_PT + j;
+        if (o >= O) continue;
+        const long idx = ((long)b * 64 + p) * O + o;
+        if (DGRAD) out[idx] = accumulate ? out[idx] + acc[j] : acc[j];
+        else out[idx] = acc[j] + bias[o];
     }
 }
 
-// dx[b][p][ci] (+)= sum_{tap,co} dy[b][p - off(tap)][co] * w[co][ci][tap]
-__global__ __launch_bounds__(256) void conv_dgrad_kernel(const float* __restrict__ w, const float* __restrict__ dy,
-                                                         float* __restrict__ dx, int B, int Ci, int Co, int T, int accumulate)
+template <bool DGRAD>
+void launch_conv_tiled(const float* w, const float* bias, const float* in, float* out, int B, int Ci, int Co, int T, int accumulate, hipStream_t s)
 {
-    const long total = (long)B * 64 * Ci;
-    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
-        const int ci = (int)(idx % Ci), pix = (int)((idx / Ci) & 63);
-        const long b = idx / ((long)Ci * 64);
-        const int py = pix >> 3, px = pix & 7;
-        float acc = 0.0f;
-        for (int t = 0; t < T; ++t) {
-            // output pixel q read input pixel q + off(t); this input pixel p feeds q = p - off(t)
-            const int oy = T == 9 ? py - (t / 3 - 1) : py, ox = T == 9 ? px - (t % 3 - 1) : px;
-            if (oy < 0 || oy > 7 || ox < 0 || ox > 7) continue;
-            const float* g = dy + (b * 64 + oy * 8 + ox) * Co;
-            const float* wk = w + (size_t)ci * T + t;
-            for (int co = 0; co < Co; ++co) acc = fmaf(g[co], wk[(size_t)co * Ci * T], acc);
-        }
-        dx[idx] = accumulate ? dx[idx] + acc : acc;
+    const int O = DGRAD ? Ci : Co;
+    if ((long)B * ((O + 15) / 16) >= 128) {
+        const dim3 grid(B, (O + 15) / 16);
+        if (T == 9) hipLaunchKernelGGL((conv_tiled_kernel<9, DGRAD, 16>), grid, dim3(256), 0, s, w, bias, in, out, Ci, Co, accumulate);
+        else hipLaunchKernelGGL((conv_tiled_kernel<1, DGRAD, 16>), grid, dim3(256), 0, s, w, bias, in, out, Ci, Co, accumulate);
+    } else {
+        const dim3 grid(B, (O + 7) / 8);
+        if (T == 9) hipLaunchKernelGGL((conv_tiled_kernel<9, DGRAD, 8>), grid, dim3(256), 0, s, w, bias, in, out, Ci, Co, accumulate);
+        else hipLaunchKernelGGL((conv_tiled_kernel<1, DGRAD, 8>), grid, dim3(256), 0, s, w, bias, in, out, Ci, Co, accumulate);
     }
 }
 
 // dw[co][ci][tap] = sum_{b,p} dy[b][p][co] * x[b][p + off(tap)][ci];  db[co] = sum dy[b][p][co]
-__global__ __launch_bounds__(256) void conv_wgrad_kernel(const float* __restrict__ dy, const float* __restrict__ x,
-                                                         float* __restrict__ dw, float* __restrict__ db,
-                                                         int B, int Ci, int Co, int T)
+// One workgroup = WG_T x WG_T (co, ci) pairs — 16 x 16 on 256 threads, or 8 x 8 on ONE WAVE when that is what it
+// takes to get 64 workgroups (64 x 64 channels); the sums over the batch stay inside one thread, in a fixed
+// order.  Thread = one pair with its T taps in registers; per board the tile's dy channels and (zero-haloed)
+// x channels go through LDS.  Sums run b-major, pixel-ascending.
+template <int T, int WG_T>
+__global__ __launch_bounds__(WG_T * WG_T) void conv_wgrad_tiled_kernel(const float* __restrict__ dy, const float* __restrict__ x,
+                                                              float* __restrict__ dw, float* __restrict__ db, int B, int Ci, int Co)
 {
-    const long total = (long)Co * Ci * T;
-    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
-        const int t = (int)(idx % T), ci = (int)((idx / T) % Ci), co = (int)(idx / ((long)T * Ci));
-        const int dyy = T == 9 ? t / 3 - 1 : 0, dxx = T == 9 ? t % 3 - 1 : 0;
-        float acc = 0.0f, bacc = 0.0f;
-        for (int b = 0; b < B; ++b)
-            for (int p = 0; p < 64; ++p) {
-                const float g = dy[((long)b * 64 + p) * Co + co];
-                bacc += g;
-                const int iy = (p >> 3) + dyy, ix = (p & 7) + dxx;
-                if (iy < 0 || iy > 7 || ix < 0 || ix > 7) continue;
-                acc = fmaf(g, x[((long)b * 64 + iy * 8 + ix) * Ci + ci], acc);
-            }
-        dw[idx] = acc;
-        if (ci == 0 && t == 0) db[co] = bacc;
+    constexpr int NPX = T == 9 ? 100 : 64, S = WG_T + 1;
+    __shared__ float dy_s[64 * S];
+    __shared__ float x_s[NPX * S];
+    const int tid = threadIdx.x, co0 = blockIdx.x * WG_T, ci0 = blockIdx.y * WG_T;
+    const int col = tid / WG_T, cil = tid % WG_T;
+    constexpr int NT = WG_T * WG_T;
+    for (int i = tid; i < NPX * S; i += NT) x_s[i] = 0.0f;
+    float acc[T];
+#pragma unroll
+    for (int t = 0; t < T; ++t) acc[t] = 0.0f;
+    float bacc = 0.0f;
+    for (int b = 0; b < B; ++b) {
+        __syncthreads();
+        for (int i = tid; i < 64 * WG_T; i += NT) {
+            const int q = i / WG_T, c = i % WG_T;
+            dy_s[q * S + c] = co0 + c < Co ? dy[((long)b * 64 + q) * Co + co0 + c] : 0.0f;
+            const int pix = T == 9 ? ((q >> 3) + 1) * 10 + (q & 7) + 1 : q;
+            x_s[pix * S + c] = ci0 + c < Ci ? x[((long)b * 64 + q) * Ci + ci0 + c] : 0.0f;
+        }
+        __syncthreads();
+        for (int q = 0; q < 64; ++q) {
+            const float g = dy_s[q * S + col];
+            bacc += g;
+            const float* xq = x_s + (T == 9 ? ((q >> 3) * 10 + (q & 7)) : q) * S + cil;     // tap (0,0) of the 3x3 window: halo offset folded in
+#pragma unroll
+            for (int t = 0; t < T; ++t) acc[t] = fmaf(g, xq[(T == 9 ? (t / 3) * 10 + t % 3 : 0) * S], acc[t]);
+        }
+    }
+    const int co = co0 + col, ci = ci0 + cil;
+    if (co < Co && ci < Ci) {
+#pragma unroll
+        for (int t = 0; t < T; ++t) dw[((size_t)co * Ci + ci) * T + t] = acc[t];
+    }
+    if (co < Co && cil == 0 && blockIdx.y == 0) db[co] = bacc;
+}
+
+// Small layers at small batch (64 x 64 channels, 8 boards): 8 x 8 pairs per workgroup and the 64 pixels of a
+// board split over 4 thread groups (16 pixels each), partial sums combined in a fixed order through LDS — 64
+// workgroups of 256 threads instead of 16, each thread's serial chain a quarter as long.
+template <int T>
+__global__ __launch_bounds__(256) void conv_wgrad_split_kernel(const float* __restrict__ dy, const float* __restrict__ x,
+                                                               float* __restrict__ dw, float* __restrict__ db, int B, int Ci, int Co)
+{
+    constexpr int NPX = T == 9 ? 100 : 64, S = 9;
+    __shared__ float dy_s[64 * S];
+    __shared__ float x_s[NPX * S];
+    __shared__ float red[3 * 64 * (T + 1)];
+    const int tid = threadIdx.x, co0 = blockIdx.x * 8, ci0 = blockIdx.y * 8;
+    const int pg = tid >> 6, pair = tid & 63, col = pair >> 3, cil = pair & 7;
+    for (int i = tid; i < NPX * S; i += 256) x_s[i] = 0.0f;
+    float acc[T];
+#pragma unroll
+    for (int t = 0; t < T; ++t) acc[t] = 0.0f;
+    float bacc = 0.0f;
+    for (int b = 0; b < B; ++b) {
+        __syncthreads();
+        for (int i = tid; i < 64 * 8; i += 256) {
+            const int q = i >> 3, c = i & 7;
+            dy_s[q * S + c] = co0 + c < Co ? dy[((long)b * 64 + q) * Co + co0 + c] : 0.0f;
+            const int pix = T == 9 ? ((q >> 3) + 1) * 10 + (q & 7) + 1 : q;
+            x_s[pix * S + c] = ci0 + c < Ci ? x[((long)b * 64 + q) * Ci + ci0 + c] : 0.0f;
+        }
+        __syncthreads();
+#pragma unroll 4
+        for (int qq = 0; qq < 16; ++qq) {
+            const int q = pg * 16 + qq;
+            const float g = dy_s[q * S + col];
+            bacc += g;
+            const float* xq = x_s + (T == 9 ? ((q >> 3) * 10 + (q & 7)) : q) * S + cil;
+#pragma unroll
+            for (int t = 0; t < T; ++t) acc[t] = fmaf(g, xq[(T == 9 ? (t / 3) * 10 + t % 3 : 0) * S], acc[t]);
+        }
+    }
+    if (pg > 0) {
+        float* r = red + ((pg - 1) * 64 + pair) * (T + 1);
+#pragma unroll
+        for (int t = 0; t < T; ++t) r[t] = acc[t];
+        r[T] = bacc;
+    }
+    __syncthreads();
+    if (pg == 0) {
+#pragma unroll
+        for (int g = 0; g < 3; ++g) {
+            const float* r = red + (g * 64 + pair) * (T + 1);
+#pragma unroll
+            for (int t = 0; t < T; ++t) acc[t] += r[t];
+            bacc += r[T];
+        }
+        const int co = co0 + col, ci = ci0 + cil;
+        if (co < Co && ci < Ci) {
+#pragma unroll
+            for (int t = 0; t < T; ++t) dw[((size_t)co * Ci + ci) * T + t] = acc[t];
+        }
+        if (co < Co && cil == 0 && blockIdx.y == 0) db[co] = bacc;
+    }
+}
+
+void launch_conv_wgrad(const float* dy, const float* x, float* dw, float* db, int B, int Ci, int Co, int T, hipStream_t s)
+{
+    if ((long)((Co + 15) / 16) * ((Ci + 15) / 16) >= 64 || B >= 32) {
+        const dim3 grid((Co + 15) / 16, (Ci + 15) / 16);
+        if (T == 9) hipLaunchKernelGGL((conv_wgrad_tiled_kernel<9, 16>), grid, dim3(256), 0, s, dy, x, dw, db, B, Ci, Co);
+        else hipLaunchKernelGGL((conv_wgrad_tiled_kernel<1, 16>), grid, dim3(256), 0, s, dy, x, dw, db, B, Ci, Co);
+    } else {
+        const dim3 grid((Co + 7) / 8, (Ci + 7) / 8);
+        if (T == 9) hipLaunchKernelGGL(conv_wgrad_split_kernel<9>, grid, dim3(256), 0, s, dy, x, dw, db, B, Ci, Co);
+        else hipLaunchKernelGGL(conv_wgrad_split_kernel<1>, grid, dim3(256), 0, s, dy, x, dw, db, B, Ci, Co);
     }
 }
 
@@ -326,7 +456,7 @@ hipError_t train_step(const TrainNet& n, const StepBuffers& sb, const float* x_i
         Saved v;
         v.in = in;
         v.y = take((size_t)N * c.Co); v.out = take((size_t)N * c.Co); v.mean = take(256); v.invstd = take(256);
-        hipLaunchKernelGGL(conv_fwd_kernel, dim3(nblocks((long)N * c.Co)), dim3(256), 0, s, P + c.w, P + c.b, in, v.y, B, c.Ci, c.Co, c.T);
+        launch_conv_tiled<false>(P + c.w, P + c.b, in, v.y, B, c.Ci, c.Co, c.T, 0, s);
         hipLaunchKernelGGL(bn_stats_kernel, dim3(c.Co), dim3(256), 0, s, v.y, v.mean, v.invstd, P + c.rm, P + c.rv, N, c.Co);
         hipLaunchKernelGGL(bn_relu_fwd_kernel, dim3(nblocks((long)N * c.Co)), dim3(256), 0, s, v.y, v.mean, v.invstd, P + c.g, P + c.be, skip, v.out,
                            (long)N * c.Co, c.Co);
@@ -338,9 +468,9 @@ hipError_t train_step(const TrainNet& n, const StepBuffers& sb, const float* x_i
         hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(c.Co), dim3(256), 0, s, dout, v.y, v.mean, v.invstd, P + c.g, P + c.be, G + c.g, G + c.be, N, c.Co);
         hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(nblocks((long)N * c.Co)), dim3(256), 0, s, dout, v.y, v.mean, v.invstd, P + c.g, P + c.be,
                            G + c.g, G + c.be, dy_tmp, (long)N * c.Co, c.Co, N);
-        hipLaunchKernelGGL(conv_wgrad_kernel, dim3(nblocks((long)c.Co * c.Ci * c.T)), dim3(256), 0, s, dy_tmp, v.in, G + c.w, G + c.b, B, c.Ci, c.Co, c.T);
+        launch_conv_wgrad(dy_tmp, v.in, G + c.w, G + c.b, B, c.Ci, c.Co, c.T, s);
         if (din)
-            hipLaunchKernelGGL(conv_dgrad_kernel, dim3(nblocks((long)N * c.Ci)), dim3(256), 0, s, P + c.w, dy_tmp, din, B, c.Ci, c.Co, c.T, acc);
+            launch_conv_tiled<true>(P + c.w, nullptr, dy_tmp, din, B, c.Ci, c.Co, c.T, acc, s);
     };
 
     // ---- forward (nn.cpp:59-91, module in train mode) ----
@@ -352,8 +482,7 @@ hipError_t train_step(const TrainNet& n, const StepBuffers& sb, const float* x_i
     const size_t tower_saved = sv.size();
     const float* pm = fwd(n.pconv, x, nullptr);             // [B][64][128]
     float* logits = take((size_t)B * KH_PSIZE);
-    hipLaunchKernelGGL(conv_fwd_kernel, dim3(nblocks((long)N * KH_POLICY_PLANES)), dim3(256), 0, s, P + n.p2w, P + n.p2b, pm, logits, B,
-                       KH_POLICY_MID, KH_POLICY_PLANES, 1);     // [B][64][73] = index pixel*73 + plane (nn.cpp:78-79)
+    launch_conv_tiled<false>(P + n.p2w, P + n.p2b, pm, logits, B, KH_POLICY_MID, KH_POLICY_PLANES, 1, 0, s);     // [B][64][73] = index pixel*73 + plane (nn.cpp:78-79)
     const float* h = fwd(n.vconv, x, nullptr);              // [B][64][1]
 
     // ---- losses and their gradients ----
@@ -372,10 +501,8 @@ hipError_t train_step(const TrainNet& n, const StepBuffers& sb, const float* x_i
     hipLaunchKernelGGL(fc_dgrad_kernel, dim3(B), dim3(64), 0, s, dpre, P + n.fcw, dh);
     bwd(n.vconv, sv[tower_saved + 1], dh, dtmp, dX, 0);
     // policy head: conv2 (plain) -> relu/bn/conv
-    hipLaunchKernelGGL(conv_wgrad_kernel, dim3(nblocks((long)KH_POLICY_PLANES * KH_POLICY_MID)), dim3(256), 0, s, dlogits, pm, G + n.p2w, G + n.p2b, B,
-                       KH_POLICY_MID, KH_POLICY_PLANES, 1);
-    hipLaunchKernelGGL(conv_dgrad_kernel, dim3(nblocks((long)N * KH_POLICY_MID)), dim3(256), 0, s, P + n.p2w, dlogits, dT, B, KH_POLICY_MID,
-                       KH_POLICY_PLANES, 1, 0);
+    launch_conv_wgrad(dlogits, pm, G + n.p2w, G + n.p2b, B, KH_POLICY_MID, KH_POLICY_PLANES, 1, s);
+    launch_conv_tiled<true>(P + n.p2w, nullptr, dlogits, dT, B, KH_POLICY_MID, KH_POLICY_PLANES, 1, 0, s);
     bwd(n.pconv, sv[tower_saved], dT, dtmp, dX, 1);
     // tower
     for (int r = n.R - 1; r >= 0; --r) {
