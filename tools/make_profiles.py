@@ -80,7 +80,7 @@ for name in ("bench_default", "bench_f16", "bench_f30", "bench_b2048", "bench_f3
     p = f"{src}/{name}.json"
     if os.path.exists(p) and os.path.getsize(p):
         shutil.copy(p, f"{dst}/{tag}_{name}.json")
-for name in ("fused_bench", "encode_bench", "host_path_bench", "clock_ramp"):
+for name in ("fused_bench", "encode_bench", "host_path_bench", "clock_ramp", "selfplay_bench", "train_bench", "wide_bench"):
     p = f"{src}/{name}.txt"
     if os.path.exists(p): shutil.copy(p, f"{dst}/{tag}_{name}.txt")
 lines = open(f"{src}/pytest_gpu.log").read().strip().splitlines()

@@ -25,6 +25,9 @@ timeout -k 10 120 python bench.py $B --filters 256 --residuals 20 --batch 256 --
 timeout -k 10 120 python tools/fused_bench.py > $O/fused_bench.txt 2>&1
 timeout -k 10 120 python tools/encode_bench.py > $O/encode_bench.txt 2>&1
 timeout -k 10 200 python tools/host_path_bench.py > $O/host_path_bench.txt 2>&1
+timeout -k 10 200 python tools/selfplay_bench.py > $O/selfplay_bench.txt 2>&1
+timeout -k 10 200 python tools/train_bench.py > $O/train_bench.txt 2>&1
+timeout -k 10 200 python tools/wide_ab.py > $O/wide_bench.txt 2>&1
 # keep only the small csv summaries of the rocprof runs (the merge-back limit is 64 MiB)
 for w in "200 20 0" "2000 20 0" "2000 2000 0" "200 20 0.3"; do set -- $w; timeout -k 10 100 python bench.py --no-cpu-baseline --steps $1 --warmup $2 --prewarm $3 2>/dev/null | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('steps', d['steps'], 'warmup', d['warmup'], 'prewarm_s', $3, 'us_per_step', round(d['ms_per_step']*1e3, 2))"; done > $O/clock_ramp.txt
 cat $O/clock_ramp.txt
