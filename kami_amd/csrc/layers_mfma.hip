@@ -15,6 +15,8 @@
 // B fragments from LDS, A fragments (pre-packed weights) through a 4-slot LDS ring fed by LDS-DMA.
 #include "kh_internal.h"
 
+#include <atomic>
+
 namespace kh {
 namespace lay {
 
@@ -514,12 +516,12 @@ __global__ __launch_bounds__(256) void value_conv_f32_kernel(const float* __rest
 template <int TAPS, int EPI> static hipError_t launch_conv_f32(const ConvArgsF32& a, hipStream_t s)
 {
     const int lds = 2 * ((TAPS == 9) ? NPIX : 64) * (a.Ci * 4 + 16);
-    static bool attr_done = false;
-    if (!attr_done) {
+    static std::atomic<bool> attr_done{ false };      // engines are called from many host threads; setting it twice is harmless
+    if (!attr_done.load(std::memory_order_acquire)) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_f32_kernel<TAPS, EPI>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) return e;
-        attr_done = true;
+        attr_done.store(true, std::memory_order_release);
     }
     hipLaunchKernelGGL((conv_f32_kernel<TAPS, EPI>), dim3((a.B + 1) / 2, a.Co / 64), dim3(256), lds, s, a);
     return hipGetLastError();
@@ -565,12 +567,12 @@ template <typename T, int TAPS, int EPI, int CPT, int RDN, int NP = 1> static hi
     const int stride = CPT * 64 * 2 + 16;                  // image of one pass
     const int image = 2 * ((TAPS == 9) ? NPIX : 64) * stride, tiles = 4 * 32 * (64 * 4 + 16);   // the epilogue's transpose tiles reuse the image
     const int lds = RDN * CHUNKB + (image > tiles ? image : tiles);
-    static bool attr_done = false;
-    if (!attr_done) {
+    static std::atomic<bool> attr_done{ false };      // engines are called from many host threads; setting it twice is harmless
+    if (!attr_done.load(std::memory_order_acquire)) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_mfma_kernel<T, TAPS, EPI, CPT, RDN, NP>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) return e;
-        attr_done = true;
+        attr_done.store(true, std::memory_order_release);
     }
     hipLaunchKernelGGL((conv_mfma_kernel<T, TAPS, EPI, CPT, RDN, NP>), dim3((a.B + 1) / 2, a.Co / 64), dim3(256), lds, s, a);
     return hipGetLastError();
