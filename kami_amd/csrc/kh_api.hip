@@ -189,20 +189,20 @@ void pack_layer(std::vector<uint16_t>& out, int dtype, const float* w, const flo
     while (out.size() % 4096) out.push_back(0);
 }
 
-// Fragments of one layer for layers_mfma.hip: [Co/64][tap][Ci/16][2][lane][8], BN scale folded in.  3x3 layers
-// with 256 (padded) input channels are laid out as two passes of 128 channels, [Co/64][pass][tap][8][2][lane][8]:
-// the kernel's two-pass variant stages half an image at a time (layers_mfma.hip).
+// Fragments of one layer for layers_mfma.hip, BN scale folded in: 8 KB chunks of 64 input channels x 64
+// output channels, [Co/64][Ci/64][tap][4][2][lane][8] — 64-channel slices of the reduction outermost, so that
+// the kernel's variants (whole image staged at once, or in passes of 64 / 128 channels) all walk the same
+// order and agree bit for bit.
 void pack_layer_generic(std::vector<uint16_t>& out, int dtype, const float* w, const float* scale,
                         int Co, int Ci, int taps, int CoP, int CiP)
 {
-    const int npass = (taps == 9 && CiP == 256) ? 2 : 1, kpp = CiP / 16 / npass;
     for (int cb = 0; cb < CoP / 64; ++cb)
-        for (int pass = 0; pass < npass; ++pass)
+        for (int slice = 0; slice < CiP / 64; ++slice)
             for (int tap = 0; tap < taps; ++tap)
-                for (int kk = 0; kk < kpp; ++kk)
+                for (int kk = 0; kk < 4; ++kk)
                     for (int ms = 0; ms < 2; ++ms)
                         for (int l = 0; l < 64; ++l) {
-                            const int r = l & 31, h = l >> 5, ks = pass * kpp + kk;
+                            const int r = l & 31, h = l >> 5, ks = slice * 4 + kk;
                             for (int j = 0; j < 8; ++j) {
                                 const int co = cb * 64 + ms * 32 + r, ci = ks * 16 + 8 * h + j;
                                 float v = 0.0f;

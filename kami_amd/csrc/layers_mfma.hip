@@ -16,6 +16,7 @@
 #include "kh_internal.h"
 
 #include <atomic>
+#include <cstdlib>
 
 namespace kh {
 namespace lay {
@@ -124,11 +125,12 @@ __device__ __forceinline__ void ring_issue(const char* stream, int nch, int c, i
 // workgroup per CU all CUs stage at the same moment (42 % of a workgroup's time at 128 channels,
 // tools/wide_stamps.py) and then leave the memory system idle.  A 2-slot ring refills the slot of the chunk
 // that is already in registers (AHEAD), so its reads must have completed before the step's barrier.
-// NP = passes over the input channels, CPT * 64 of them each (256 channels as 2 x 128: the image of one pass is
-// half the size, so that the two-workgroup variant exists there too; the 256-channel weights are packed
-// pass-major for every variant, see chunk_off).
+// NP = passes over the input channels, CPT * 64 of them each: the image of one pass is 1/NP the size (256
+// channels as 2 x 128: two workgroups per CU there too; passes of 64 channels: image + ring = 50 944 B, THREE
+// workgroups per CU at 168 registers).  Weights are packed in 64-channel slices (kh_api.hip: pack_layer_generic),
+// the order every variant walks (chunk_off).
 template <typename T, int TAPS, int EPI, int CPT, int RDN = RD, int NP = 1>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, RDN == 2 ? 2 : 1))) void conv_mfma_kernel(ConvArgs a)
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, RDN == 2 ? (CPT == 1 ? 3 : 2) : 1))) void conv_mfma_kernel(ConvArgs a)
 {
     constexpr int AHEAD = RDN == 2 ? 1 : 0;
     constexpr int LDS_IMG = RDN * CHUNKB;
@@ -224,11 +226,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, RDN == 2
             acc[ms][4 * g + 0] = s.x; acc[ms][4 * g + 1] = s.y; acc[ms][4 * g + 2] = s.z; acc[ms][4 * g + 3] = s.w;
         }
     // byte offset of the first k-step of chunk n (of a pass) in the image, relative to b_base (a constant after
-    // unrolling).  Chunks are tap-major, 64 channels each — except 256-channel 3x3 layers, which are packed as
-    // two 128-channel passes (kh_api.hip: pack_layer_generic): the one-pass variant walks that order too.
+    // unrolling): chunks come in 64-channel slices, all taps of a slice before the next slice
     auto chunk_off = [](int n) -> unsigned {
-        int tap = n / CPT, q = n - tap * CPT;
-        if (TAPS == 9 && CPT == 4 && NP == 1) { tap = (n % 18) / 2; q = (n / 18) * 2 + (n & 1); }
+        const int q = n / TAPS, tap = n - q * TAPS;
         return ((TAPS == 9) ? (unsigned)(((tap / 3) * PITCH + (tap % 3)) * stride) : 0u) + q * 128;
     };
     V A[2][8], Bq[2][4];
@@ -580,15 +580,20 @@ template <typename T, int TAPS, int EPI, int CPT, int RDN, int NP = 1> static hi
 
 template <typename T, int TAPS, int EPI, int CPT> static hipError_t launch_conv_cpt(const ConvArgs& a, hipStream_t s)
 {
-    // 3x3 layers with more workgroups than CUs: the 2-slot-ring variant, two workgroups per CU (128 input
-    // channels; 256 as two passes of 128).  10x128 at batch 1024: 726 -> 600 us per forward; with one
-    // workgroup per CU anyway it only costs (219 -> 251 us at batch 256), so this is decided per launch.
-    const bool crowded = (long)((a.B + 1) / 2) * (a.Co / 64) > 256;
+    // 3x3 layers with more workgroups than CUs: the 2-slot-ring variants, two workgroups per CU (128 input
+    // channels; 256 as two passes of 128) or three (passes of 64 channels) when there are enough of them.
+    // 10x128 at batch 1024: 726 -> 600 us per forward with two; with one workgroup per CU anyway the short ring
+    // only costs (219 -> 251 us at batch 256), so this is decided per launch.
+    const long wgs = (long)((a.B + 1) / 2) * (a.Co / 64);
+    static const int force = getenv("KAMI_WIDE_VARIANT") ? atoi(getenv("KAMI_WIDE_VARIANT")) : 0;   // experiments: 1, 2, 3 workgroups per CU
+    const int per_cu = force ? force : (wgs > 512 ? 3 : (wgs > 256 ? 2 : 1));
     if constexpr (TAPS == 9 && CPT == 2) {
-        if (crowded) return launch_conv_rd<T, TAPS, EPI, 2, 2>(a, s);
+        if (per_cu == 3) return launch_conv_rd<T, TAPS, EPI, 1, 2, 2>(a, s);
+        if (per_cu == 2) return launch_conv_rd<T, TAPS, EPI, 2, 2>(a, s);
     }
     if constexpr (TAPS == 9 && CPT == 4) {
-        if (crowded) return launch_conv_rd<T, TAPS, EPI, 2, 2, 2>(a, s);
+        if (per_cu == 3) return launch_conv_rd<T, TAPS, EPI, 1, 2, 4>(a, s);
+        if (per_cu == 2) return launch_conv_rd<T, TAPS, EPI, 2, 2, 2>(a, s);
     }
     return launch_conv_rd<T, TAPS, EPI, CPT, RD>(a, s);
 }
