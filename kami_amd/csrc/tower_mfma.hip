@@ -297,26 +297,10 @@ __device__ __forceinline__ void gemm_layer(Pipe& p, const char* smem, int wave, 
             __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);
         } else {
 #pragma unroll
-#if defined(KAMI_SGB_EVEN) || defined(KAMI_SGB_ODD)
-            for (int i = 0; i < 4; ++i) {
-#if defined(KAMI_SGB_EVEN)
-                __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
-                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-#else
-                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
-                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-#endif
-            }
-#else
             for (int i = 0; i < 8; ++i) {
                 __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);   // DS read
                 __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // MFMA
             }
-#endif
         }
     }
 }
