@@ -109,9 +109,16 @@ public:
         if (!actions_utd) {
             chess::Move mv[chess::MAX_MOVES];
             const int n = position().legal(mv);
-            cur_actions.clear();
-            for (int i = 0; i < n; ++i) cur_actions.push_back(encode(mv[i]));
-            std::sort(cur_actions.begin(), cur_actions.end());
+            // ascending codes by insertion: ~30 codes that arrive in runs (the generator goes piece type by piece
+            // type, squares in order), a quarter of std::sort's time here
+            int code[chess::MAX_MOVES];
+            for (int i = 0; i < n; ++i) {
+                const int c = encode(mv[i]);
+                int j = i;
+                for (; j > 0 && code[j - 1] > c; --j) code[j] = code[j - 1];
+                code[j] = c;
+            }
+            cur_actions.assign(code, code + n);
             // under-promotions and the queen promotion of one pawn move share nothing; but two moves can
             // never share a code either (src and type identify the destination and the piece)
             actions_utd = true;
