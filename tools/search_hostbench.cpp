@@ -35,7 +35,16 @@ int main(int argc, char** argv)
             if (!have[g]) continue;
             if (g + 2 < games && have[g + 2]) trees[g + 2]->prefetch_expand(leaves[g + 2]);
             const size_t na = leaves[g].actions.size();
-            for (size_t i = 0; i < na; ++i) pri[i] = 1.0f / (float)na;
+            // peaked pseudo-priors (a network's are far from uniform; uniform ones make every PUCT choice a tie)
+            uint64_t hsh = leaves[g].record.piece_occ[0] * 0x9e3779b97f4a7c15ull ^ leaves[g].record.color_occ[0];
+            float tot = 0.0f;
+            for (size_t i = 0; i < na; ++i) {
+                hsh = hsh * 6364136223846793005ull + 1442695040888963407ull;
+                const float u = (float)(hsh >> 40) * (1.0f / 16777216.0f);
+                pri[i] = u * u * u * u + 0.01f;
+                tot += pri[i];
+            }
+            for (size_t i = 0; i < na; ++i) pri[i] /= tot;
             const float v = (float)((leaves[g].record.piece_occ[0] * 0x9e3779b97f4a7c15ull >> 40) % 2001) / 1000.0f - 1.0f;
             trees[g]->expand_leaf(leaves[g], pri, v * 0.2f);
             ++evals;
