@@ -586,12 +586,15 @@ template <typename T, int TAPS, int EPI, int CPT> static hipError_t launch_conv_
     // only costs (219 -> 251 us at batch 256), so this is decided per launch.
     const long wgs = (long)((a.B + 1) / 2) * (a.Co / 64);
     static const int force = getenv("KAMI_WIDE_VARIANT") ? atoi(getenv("KAMI_WIDE_VARIANT")) : 0;   // experiments: 1, 2, 3 workgroups per CU
-    const int per_cu = force ? force : (wgs > 512 ? 3 : (wgs > 256 ? 2 : 1));
+    // measured (tools/wide_variants.py): 128 channels: three per CU is ahead from 512 workgroups on (+2 %, +14 % at
+    // 2048); 256 channels: two and three are within 2 % of each other either way
     if constexpr (TAPS == 9 && CPT == 2) {
+        const int per_cu = force ? force : (wgs > 256 ? 3 : 1);
         if (per_cu == 3) return launch_conv_rd<T, TAPS, EPI, 1, 2, 2>(a, s);
         if (per_cu == 2) return launch_conv_rd<T, TAPS, EPI, 2, 2>(a, s);
     }
     if constexpr (TAPS == 9 && CPT == 4) {
+        const int per_cu = force ? force : (wgs > 256 ? 2 : 1);
         if (per_cu == 3) return launch_conv_rd<T, TAPS, EPI, 1, 2, 4>(a, s);
         if (per_cu == 2) return launch_conv_rd<T, TAPS, EPI, 2, 2, 2>(a, s);
     }
