@@ -112,7 +112,6 @@ def main():
     local_rank = dev_index
     torch.cuda.set_device(dev_index)
     dist = kd.init(backend)         # RCCL; only the barrier and the max-over-ranks use it
-    red_dev = "cuda" if backend == "nccl" else "cpu"
 
     F, Cc, R, B = a.features, a.filters, a.residuals, a.batch
     nn = NN(8, 8, F, 4672, filters=Cc, residuals=R, dtype=a.dtype, device=local_rank)
@@ -155,7 +154,7 @@ def main():
     torch.cuda.synchronize()
     barrier()
     dt = time.perf_counter() - t0
-    dt = kd.max_over_ranks(dist, dt, device=red_dev)
+    dt = kd.max_over_ranks(dist, dt)
     assert bool(torch.isfinite(policy).all()) and abs(float(policy[0].sum()) - 1.0) < 1e-2
 
     # roofline of the dominant kernel (the forward pass), HIP events on the engine's own stream

@@ -121,6 +121,17 @@ typedef struct kh_train_config {
 int  kh_train(kh_engine* e, const float* inputs, const float* obs_p, const float* obs_v, int trajectories,
               const kh_train_config* cfg, float* first_loss, float* last_loss);
 
+/* NN::read nn.cpp:204-222: parse a checkpoint file without an engine.  Two containers are understood:
+ * the reference's own — the libtorch archive NN::write leaves (nn.cpp:189-202: module.save + the
+ * "generation" IValue), read here with a zip walk and a pickle stack machine (csrc/torch_archive.h; no
+ * libtorch, nothing from the file is executed) — and the engine's "KAMW" container (32-byte header + blob).
+ * Fills the network shape, generation and *nfloats; when `blob` is non-NULL (capacity `cap` floats) also the
+ * parameters in blob order (BatchNorm num_batches_tracked counters are not part of the blob).  No GPU needed. */
+int  kh_checkpoint_read(const char* path, int* features, int* filters, int* residuals, int* generation,
+                        float* blob, size_t cap, size_t* nfloats);
+/* NN::read as a whole: kh_checkpoint_read + shape check against cfg + kh_load_weights. */
+int  kh_load_checkpoint(kh_engine* e, const char* path);
+
 /* The engine's current fp32 parameter set in blob order (what NN::write would serialise, nn.cpp:189-202). */
 int  kh_get_weights(kh_engine* e, float* blob, size_t nfloats);
 

@@ -41,6 +41,9 @@ SYMBOLS = {
     "kh_destroy": (None, [_P]),
     "kh_load_weights": (C.c_int, [_P, _P, C.c_size_t, C.c_int]),
     "kh_train": (C.c_int, [_P, _P, _P, _P, C.c_int, C.POINTER(TrainConfig), C.POINTER(C.c_float), C.POINTER(C.c_float)]),
+    "kh_checkpoint_read": (C.c_int, [C.c_char_p, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int),
+                                     _P, C.c_size_t, C.POINTER(C.c_size_t)]),
+    "kh_load_checkpoint": (C.c_int, [_P, C.c_char_p]),
     "kh_get_weights": (C.c_int, [_P, _P, C.c_size_t]),
     "kh_generation": (C.c_int, [_P]),
     "kh_clone": (C.c_int, [_P, C.POINTER(_P)]),

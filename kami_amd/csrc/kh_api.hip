@@ -5,6 +5,7 @@
 // Env::observe (kami/env.h:202-262).  There is no CPU fallback anywhere in this library:
 // without a gfx950 device kh_create fails with KH_ERR_NO_DEVICE.
 #include "kh_internal.h"
+#include "torch_archive.h"
 
 #include <atomic>
 #include <cmath>
@@ -866,6 +867,92 @@ int kh_train(kh_engine* e, const float* inputs, const float* obs_p, const float*
     if (first_loss) *first_loss = firstloss;
     if (last_loss) *last_loss = lastloss;
     return kh_load_weights(e, blob.data(), nfl, W->generation + 1);         // nn.cpp:371 ++generation
+}
+
+int kh_checkpoint_read(const char* path, int* features, int* filters, int* residuals, int* generation,
+                       float* blob, size_t cap, size_t* nfloats)
+{
+    if (!path) return fail(KH_ERR_INVALID, "null path");
+    FILE* f = fopen(path, "rb");
+    if (!f) return fail(KH_ERR_INVALID, "cannot open %s", path);
+    int32_t hdr[8] = { 0 };
+    const size_t got = fread(hdr, 1, sizeof hdr, f);
+    int F = 0, C = 0, R = 0, gen = 0;
+    std::vector<float> data;
+    if (got == sizeof hdr && hdr[0] == 0x574d414b /* "KAMW" */) {
+        F = hdr[1]; C = hdr[2]; R = hdr[3]; gen = hdr[4];
+        if (F < 1 || F > 4096 || C < 1 || C > 1024 || R < 0 || R > 256) { fclose(f); return fail(KH_ERR_INVALID, "%s: bad header", path); }
+        data.resize(kh_weight_count(F, C, R));
+        const size_t n = fread(data.data(), 4, data.size(), f);
+        fclose(f);
+        if (n != data.size()) return fail(KH_ERR_INVALID, "%s: truncated", path);
+    } else {
+        fclose(f);
+        if (got < 4 || memcmp(hdr, "PK\003\004", 4) != 0)
+            return fail(KH_ERR_INVALID, "%s is neither a libtorch archive nor an engine weight blob", path);
+        try {
+            kh_archive::Checkpoint ck = kh_archive::read_checkpoint(path);
+            auto w = ck.tensors.find("conv1.weight");
+            auto g = ck.ints.find("generation");
+            if (w == ck.tensors.end() || w->second.shape.size() != 4 || g == ck.ints.end())
+                return fail(KH_ERR_INVALID, "%s: not a kami checkpoint (no conv1.weight / generation)", path);
+            C = (int)w->second.shape[0]; F = (int)w->second.shape[1]; gen = (int)g->second;
+            while (ck.tensors.count("residual" + std::to_string(R) + ".conv1.weight")) ++R;
+            // blob order of kh_weight_count (names per nn.cpp:20-23,45-56)
+            std::vector<std::pair<std::string, size_t>> order;
+            auto convbn = [&](const std::string& conv, const std::string& bn, size_t co, size_t ci, size_t k) {
+                order.emplace_back(conv + ".weight", co * ci * k * k); order.emplace_back(conv + ".bias", co);
+                for (const char* s : { ".weight", ".bias", ".running_mean", ".running_var" }) order.emplace_back(bn + s, co);
+            };
+            convbn("conv1", "batchnorm1", C, F, 3);
+            for (int i = 0; i < R; ++i) {
+                const std::string r = "residual" + std::to_string(i);
+                convbn(r + ".conv1", r + ".batchnorm1", C, C, 3);
+                convbn(r + ".conv2", r + ".batchnorm2", C, C, 3);
+            }
+            convbn("policyconv", "pbatchnorm", KH_POLICY_MID, C, 1);
+            order.emplace_back("policyconv2.weight", (size_t)KH_POLICY_PLANES * KH_POLICY_MID);
+            order.emplace_back("policyconv2.bias", KH_POLICY_PLANES);
+            convbn("valueconv", "vbatchnorm", 1, C, 1);
+            order.emplace_back("valuefc.weight", (size_t)KH_VALUE_WIDTH * 64);
+            order.emplace_back("valuefc.bias", KH_VALUE_WIDTH);
+            if (order.size() != ck.tensors.size())
+                return fail(KH_ERR_INVALID, "%s: %zu tensors, this network has %zu", path, ck.tensors.size(), order.size());
+            for (auto& o : order) {
+                auto t = ck.tensors.find(o.first);
+                if (t == ck.tensors.end() || t->second.data.size() != o.second)
+                    return fail(KH_ERR_INVALID, "%s: tensor %s missing or of the wrong size", path, o.first.c_str());
+                data.insert(data.end(), t->second.data.begin(), t->second.data.end());
+            }
+        } catch (const std::exception& ex) {
+            return fail(KH_ERR_INVALID, "%s: %s", path, ex.what());
+        }
+    }
+    if (features) *features = F;
+    if (filters) *filters = C;
+    if (residuals) *residuals = R;
+    if (generation) *generation = gen;
+    if (nfloats) *nfloats = data.size();
+    if (blob) {
+        if (cap < data.size()) return fail(KH_ERR_INVALID, "blob buffer holds %zu floats, the checkpoint has %zu", cap, data.size());
+        memcpy(blob, data.data(), data.size() * sizeof(float));
+    }
+    return KH_OK;
+}
+
+int kh_load_checkpoint(kh_engine* e, const char* path)
+{
+    if (!e) return fail(KH_ERR_INVALID, "null engine");
+    int F, C, R, gen;
+    size_t n = 0;
+    int rc = kh_checkpoint_read(path, &F, &C, &R, &gen, nullptr, 0, &n);
+    if (rc) return rc;
+    if (F != e->cfg.features || C != e->cfg.filters || R != e->cfg.residuals)
+        return fail(KH_ERR_INVALID, "%s holds a %d-plane %dx%d network, this engine is %d-plane %dx%d", path, F, R, C,
+                    e->cfg.features, e->cfg.residuals, e->cfg.filters);
+    std::vector<float> blob(n);
+    if ((rc = kh_checkpoint_read(path, nullptr, nullptr, nullptr, nullptr, blob.data(), blob.size(), nullptr))) return rc;
+    return kh_load_weights(e, blob.data(), blob.size(), gen);
 }
 
 int kh_get_weights(kh_engine* e, float* blob, size_t nfloats)

@@ -32,8 +32,10 @@ def records_to_arrays(nn, records):
 
 
 def generation(nn, pool, replay: ReplayBuffer, *, play_evals: int, play_seconds: float = 60.0, sample: int | None = None,
-               mlr: int = 5, epochs: int = 8, batchsize: int = 8, dist=None, device: str = "cpu"):
-    """Play, collect, train (rank 0), publish.  Returns a dict of what happened."""
+               mlr: int = 5, epochs: int = 8, batchsize: int = 8, dist=None, device: str | None = None):
+    """Play, collect, train (rank 0), publish.  Returns a dict of what happened.  The collectives' tensors live where
+    the group's backend needs them (kd.collective_device: device memory for RCCL, host memory for gloo)."""
+    device = device or kd.collective_device(dist)
     import ctypes as C
     from . import search as S
     from .replay import gather_compact

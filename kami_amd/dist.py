@@ -18,10 +18,12 @@ def env_rank() -> Tuple[int, int, int]:
             int(os.environ.get("WORLD_SIZE", "1")))
 
 
-def init(backend: str | None = None):
-    """Initialise the default process group when WORLD_SIZE > 1; returns torch.distributed or None."""
+def init(backend: str | None = None, single_rank_group: bool = False):
+    """Initialise the default process group when WORLD_SIZE > 1; returns torch.distributed or None.
+    single_rank_group: also build the group for a lone process (a world of one still goes through the backend —
+    how the RCCL code path is exercised on a one-GPU box)."""
     rank, local_rank, world = env_rank()
-    if world <= 1:
+    if world <= 1 and not single_rank_group:
         return None
     import torch
     import torch.distributed as dist
@@ -32,10 +34,20 @@ def init(backend: str | None = None):
     if backend is None:
         backend = "nccl" if torch.cuda.is_available() else "gloo"
     if backend == "nccl":
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        dev = local_rank % max(1, torch.cuda.device_count())
+        torch.cuda.set_device(dev)
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", dev))
     else:
-        dist.init_process_group(backend)
+        dist.init_process_group(backend, rank=rank, world_size=world)
     return dist
+
+
+def collective_device(dist) -> str:
+    """Where a collective's tensors must live: RCCL ("nccl") only takes device tensors, gloo host tensors.
+    Every helper below derives it from the group's backend instead of trusting a caller's default."""
+    if dist is None:
+        return "cpu"
+    return "cuda" if str(dist.get_backend()).lower() == "nccl" else "cpu"
 
 
 def shard(n_units: int, rank: int, world: int) -> Tuple[int, int]:
@@ -50,16 +62,17 @@ def barrier(dist) -> None:
         dist.barrier()
 
 
-def max_over_ranks(dist, value: float, device: str = "cpu") -> float:
+def max_over_ranks(dist, value: float, device: str | None = None) -> float:
     if dist is None:
         return value
     import torch
+    device = device or collective_device(dist)
     t = torch.tensor([value], dtype=torch.float64, device=device)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return float(t.item())
 
 
-def broadcast_weights(dist, blob, generation: int, src: int = 0, device: str = "cpu"):
+def broadcast_weights(dist, blob, generation: int, src: int = 0, device: str | None = None):
     """New parameters from the trainer rank to every evaluator rank: the multi-process counterpart
     of `model->read(path)` after a candidate is accepted (selfplay.cpp:282-283).  One collective
     of the whole blob (2 MB for 6x64, 95 MB for 20x256) plus the generation; RCCL over xGMI with
@@ -68,6 +81,7 @@ def broadcast_weights(dist, blob, generation: int, src: int = 0, device: str = "
     import torch
     if dist is None:
         return np.ascontiguousarray(blob, dtype=np.float32), generation
+    device = device or collective_device(dist)
     meta = torch.tensor([generation, 0 if blob is None else int(np.asarray(blob).size)], dtype=torch.int64, device=device)
     dist.broadcast(meta, src=src)
     n = int(meta[1].item())

@@ -7,6 +7,7 @@
 #include <cmath>
 #include <cstdint>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <fstream>
 #include <iostream>
@@ -33,6 +34,19 @@ int dtype_from_options()
     if (d == "f32" || d == "fp32") return KH_F32;
     if (d == "f16" || d == "fp16") return KH_F16;
     return KH_BF16;
+}
+
+// The reference pins kCUDA:0 (nn.cpp:121).  Here one kami process drives one GPU of the node: option key
+// "engine_device", else the launcher's LOCAL_RANK (torchrun / mpirun style), modulo the visible devices.
+int device_from_options()
+{
+    int dev = options::getInt("engine_device", -1);
+    if (dev < 0) {
+        const char* lr = getenv("LOCAL_RANK");
+        dev = lr ? atoi(lr) : 0;
+    }
+    const int n = kh_device_count();
+    return n > 0 ? ((dev % n) + n) % n : 0;
 }
 
 // libtorch-default-like initialisation for a fresh model (the reference's fresh NN is random
@@ -77,7 +91,8 @@ void NN::create(int dtype)
     std::memset(&cfg, 0, sizeof cfg);
     cfg.width = width; cfg.height = height; cfg.features = features; cfg.psize = psize;
     cfg.filters = filters; cfg.residuals = residuals;
-    cfg.dtype = dtype; cfg.value_mode = KH_VALUE_REFERENCE_FLAT; cfg.device = 0;
+    cfg.dtype = dtype; cfg.value_mode = KH_VALUE_REFERENCE_FLAT; cfg.device = device_from_options();
+    device.index = cfg.device;
     int rc = kh_create(&cfg, &eng);
     if (rc) raise(rc);
 }
@@ -171,20 +186,20 @@ void NN::write(std::string path)
     std::cout << "Saved model to " << path << std::endl;          // nn.cpp:201
 }
 
+// nn.cpp:204-222.  Reads what the reference's NN::write leaves on disk — a libtorch archive (module.save +
+// the "generation" IValue), parsed by the engine without libtorch (kh_checkpoint_read) — as well as the
+// engine's own KAMW container that write() above produces.
 void NN::read(std::string path)
 {
-    std::ifstream f(path, std::ios::binary);
-    if (!f) throw std::runtime_error("cannot open " + path);
-    int32_t hdr[8];
-    f.read(reinterpret_cast<char*>(hdr), sizeof hdr);
-    if (!f || hdr[0] != MAGIC)
-        throw std::runtime_error(path + " is not an engine weight blob (torch archives are not read by this engine)");
-    if (hdr[1] != features || hdr[2] != filters || hdr[3] != residuals)
+    int F = 0, C = 0, R = 0, gen = 0;
+    size_t n = 0;
+    int rc = kh_checkpoint_read(path.c_str(), &F, &C, &R, &gen, nullptr, 0, &n);
+    if (rc) raise(rc);
+    if (F != features || C != filters || R != residuals)
         throw std::runtime_error(path + ": network shape does not match this NN");
-    std::vector<float> blob(kh_weight_count(features, filters, residuals));
-    f.read(reinterpret_cast<char*>(blob.data()), (std::streamsize)(blob.size() * sizeof(float)));
-    if (!f) throw std::runtime_error(path + ": truncated");
-    load_blob(blob.data(), blob.size(), hdr[4]);
+    std::vector<float> blob(n);
+    if ((rc = kh_checkpoint_read(path.c_str(), nullptr, nullptr, nullptr, nullptr, blob.data(), blob.size(), nullptr))) raise(rc);
+    load_blob(blob.data(), blob.size(), gen);
 }
 
 NN* NN::clone() { return new NN(this); }

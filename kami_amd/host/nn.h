@@ -11,7 +11,9 @@
 //   - "filters" / "residuals" come from kami::options like the reference's module (nn.cpp:42-43).
 // Differences, on purpose: the engine only exists on the GPU (isCUDA() is always true, there is
 // no force_cpu path: construction throws without an MI355X); train() runs the reference's SGD loop on
-// the device in fp32 (kh_train); read()/write() use the engine's own blob format (kami_amd/weights.py).
+// the device in fp32 (kh_train); read() takes the reference's own libtorch checkpoints (parsed without
+// libtorch, kh_checkpoint_read) and the engine's KAMW blobs, write() produces KAMW (kami_amd/weights.py);
+// the GPU is option "engine_device" / LOCAL_RANK instead of the reference's fixed kCUDA:0 (nn.cpp:121).
 #pragma once
 
 #include <string>

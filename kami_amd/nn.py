@@ -38,6 +38,18 @@ def _ptr(a: np.ndarray):
     return a.ctypes.data_as(C.c_void_p)
 
 
+def read_checkpoint(path: str):
+    """kh_checkpoint_read: -> (blob, features, filters, residuals, generation) of a checkpoint file — a libtorch
+    archive written by the reference's NN::write (nn.cpp:189-202) or an engine KAMW blob.  Needs no GPU."""
+    lib = L.load()
+    F, Cc, R, gen, n = C.c_int(), C.c_int(), C.c_int(), C.c_int(), C.c_size_t()
+    p = path.encode()
+    _chk(lib.kh_checkpoint_read(p, C.byref(F), C.byref(Cc), C.byref(R), C.byref(gen), None, 0, C.byref(n)))
+    blob = np.empty(n.value, np.float32)
+    _chk(lib.kh_checkpoint_read(p, None, None, None, None, _ptr(blob), blob.size, None))
+    return blob, F.value, Cc.value, R.value, gen.value
+
+
 class NN:
     def __init__(self, width: int = 8, height: int = 8, features: int = NFEATURES,
                  psize: int = PSIZE, *, filters: int = 256, residuals: int = 2,
@@ -103,16 +115,16 @@ class NN:
         return policy, value
 
     def read(self, path: str) -> None:
-        blob, F, Cc, R, gen = W.load(path)
+        """NN::read (nn.cpp:204-222): the reference's own libtorch archives and the engine's KAMW blobs."""
+        blob, F, Cc, R, gen = read_checkpoint(path)
         if (F, Cc, R) != (self.cfg.features, self.cfg.filters, self.cfg.residuals):
             raise KamiError(L.KH_ERR_INVALID, "checkpoint shape does not match this NN")
         self.load_weights(blob, gen)
 
     def write(self, path: str) -> None:
-        if self._blob is None:
-            raise KamiError(L.KH_ERR_NO_WEIGHTS, "no weights loaded")
-        W.save(path, self._blob, self.cfg.features, self.cfg.filters, self.cfg.residuals,
-               self.get_generation())
+        """NN::write (nn.cpp:189-202) into the engine's KAMW container (read() takes it back, and the reference's own
+        archives as well)."""
+        W.save(path, self.get_weights(), self.cfg.features, self.cfg.filters, self.cfg.residuals, self.get_generation())
 
     def clone(self) -> "NN":
         other = object.__new__(NN)

@@ -59,7 +59,7 @@ class ReplayBuffer:
         rec[:, -1] = self.result_buffer[idx]
         return rec
 
-    def gather(self, dist, root: int = 0, device: str = "cpu") -> int:
+    def gather(self, dist, root: int = 0, device: str | None = None) -> int:
         """Merge every rank's fresh records into `root`'s ring.  Returns how many records the
         root inserted (0 on the other ranks)."""
         import torch
@@ -67,6 +67,8 @@ class ReplayBuffer:
         self._fresh = []
         if dist is None:
             return 0
+        from .dist import collective_device
+        device = device or collective_device(dist)
         world, rank = dist.get_world_size(), dist.get_rank()
         counts = torch.zeros(world, dtype=torch.int64, device=device)
         counts[rank] = mine.shape[0]
@@ -92,7 +94,7 @@ class ReplayBuffer:
         return inserted
 
 
-def gather_compact(dist, payload: bytes, record_bytes: int, root: int = 0, device: str = "cpu"):
+def gather_compact(dist, payload: bytes, record_bytes: int, root: int = 0, device: str | None = None):
     """Merge fixed-size compact records (ks_record, 664 bytes: board + sparse visit distribution + value —
     include/kami_search.h) over the ranks: 40x less traffic than the dense 26 372-byte rows `gather` moves.
     Every rank passes its own records; returns the list of every rank's payload (rank-major) on `root`, and
@@ -101,6 +103,8 @@ def gather_compact(dist, payload: bytes, record_bytes: int, root: int = 0, devic
     import torch
     if dist is None:
         return [payload]
+    from .dist import collective_device
+    device = device or collective_device(dist)
     world, rank = dist.get_world_size(), dist.get_rank()
     assert len(payload) % record_bytes == 0
     counts = torch.zeros(world, dtype=torch.int64, device=device)

@@ -124,6 +124,23 @@ def gen_train(tmp):
         print("train fixture:", name, "max |delta w|", float(np.abs(trained - blob).max()))
 
 
+def gen_checkpoint(tmp):
+    """A checkpoint exactly as kami leaves it on disk: the blob of the net_f30_c8_r1 fixture pushed through the
+    reference's NN::read and written by its own NN::write (nn.cpp:189-222; `kami_ref export`), and the same
+    file converted back by the reference (`kami_ref convert`) as the cross-check of the cross-check."""
+    name, F, C, R, B, seed, peaky, kind = NETS[0]
+    blob = W.random_weights(F, C, R, seed=seed, peaky=peaky)
+    wpath = os.path.join(tmp, "w.bin")
+    W.save(wpath, blob, F, C, R, 7)
+    out = os.path.join(OUT, f"ref_checkpoint_f{F}_c{C}_r{R}.pt")
+    subprocess.check_call([REF, "export", wpath, out], stdout=subprocess.DEVNULL)
+    back = os.path.join(tmp, "back.bin")
+    subprocess.check_call([REF, "convert", out, str(F), str(C), str(R), back], stdout=subprocess.DEVNULL)
+    b2, F2, C2, R2, g2 = W.load(back)
+    assert (F2, C2, R2, g2) == (F, C, R, 7) and np.array_equal(b2, blob)
+    print("checkpoint fixture:", out, os.path.getsize(out), "bytes")
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     if not os.path.exists(REF):
@@ -135,8 +152,12 @@ def main():
         if "--train-only" in sys.argv:
             gen_train(tmp)
             return
+        if "--checkpoint-only" in sys.argv:
+            gen_checkpoint(tmp)
+            return
         gen_search(tmp)
         gen_train(tmp)
+        gen_checkpoint(tmp)
         recs = gen_observe(tmp)
         planes = recs["obs"].reshape(-1, 8, 8, 30)
         for name, F, C, R, B, seed, peaky, kind in NETS:

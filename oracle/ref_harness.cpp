@@ -17,6 +17,9 @@
 //                                                   trained parameters + BatchNorm statistics in blob order
 //   mcts    <nodes> <nmoves> <out.txt>              the reference's own MCTS (kami/mcts.h) under a
 //                                                   deterministic synthetic evaluator, noise off
+//   export  <weights.bin> <out.pt>                  blob -> a checkpoint written by the reference's own NN::write
+//                                                   (nn.cpp:189-202): the torch archive an existing kami model is
+//   convert <archive.pt> <F> <C> <R> <out.bin>      NN::read (nn.cpp:204-222) of such an archive -> KAMW blob
 #include "kami/nn/nn.h"
 #include "kami/env.h"
 #include "kami/mcts.h"
@@ -343,9 +346,70 @@ static int cmd_mcts(int argc, char** argv)
     return 0;
 }
 
+static void write_kamw(const char* path, int F, int C, int R, int gen, const std::vector<float>& blob)
+{
+    int32_t h[8] = { 0x574d414b, F, C, R, gen, 0, 0, 0 };
+    FILE* f = fopen(path, "wb");
+    if (!f || fwrite(h, 4, 8, f) != 8 || fwrite(blob.data(), 4, blob.size(), f) != blob.size()) { fprintf(stderr, "cannot write %s\n", path); exit(2); }
+    fclose(f);
+}
+
+// blob -> reference checkpoint: the module is filled from the blob, ingested by NN::read and written
+// back by the reference's own NN::write, so the file is byte for byte what kami leaves on disk.
+static int cmd_export(int argc, char** argv)
+{
+    if (argc < 4) return 1;
+    Blob b = read_blob(argv[2]);
+    options::setInt("filters", b.C);
+    options::setInt("residuals", b.R);
+    auto mod = std::make_shared<NNModule>(8, 8, b.F, PSIZE);
+    fill_module(*mod, b);
+    std::string tmp = std::string(argv[3]) + ".tmp";
+    {
+        torch::serialize::OutputArchive a;
+        mod->save(a);
+        a.write("generation", torch::IValue(b.gen));
+        a.save_to(tmp);
+    }
+    NN net(8, 8, b.F, PSIZE, /*force_cpu=*/true);
+    net.read(tmp);
+    remove(tmp.c_str());
+    net.write(argv[3]);                                            // nn.cpp:189-202
+    return 0;
+}
+
+static int cmd_convert(int argc, char** argv)
+{
+    if (argc < 7) return 1;
+    const int F = atoi(argv[3]), C = atoi(argv[4]), R = atoi(argv[5]);
+    options::setInt("filters", C);
+    options::setInt("residuals", R);
+    NN net(8, 8, F, PSIZE, /*force_cpu=*/true);
+    net.read(argv[2]);                                             // nn.cpp:204-222
+    // NN keeps its module private: re-load the archive into a module of the same class to walk the tensors
+    auto out = std::make_shared<NNModule>(8, 8, F, PSIZE);
+    {
+        torch::serialize::InputArchive a;
+        a.load_from(argv[2]);
+        out->load(a);
+    }
+    auto params = out->named_parameters(true);
+    auto bufs = out->named_buffers(true);
+    std::vector<float> blob;
+    for (auto& name : canonical_names(R)) {
+        torch::Tensor t = params.contains(name) ? params[name] : bufs[name];
+        t = t.contiguous().to(torch::kFloat32);
+        const float* p = t.data_ptr<float>();
+        blob.insert(blob.end(), p, p + t.numel());
+    }
+    write_kamw(argv[6], F, C, R, net.get_generation(), blob);
+    printf("generation %d floats %zu\n", net.get_generation(), blob.size());
+    return 0;
+}
+
 int main(int argc, char** argv)
 {
-    if (argc < 2) { fprintf(stderr, "usage: kami_ref infer|observe|bench|games|mcts ...\n"); return 1; }
+    if (argc < 2) { fprintf(stderr, "usage: kami_ref infer|observe|bench|games|mcts|train|export|convert ...\n"); return 1; }
     std::string c = argv[1];
     try {
         if (c == "infer") return cmd_infer(argc, argv);
@@ -354,6 +418,8 @@ int main(int argc, char** argv)
         if (c == "games") return cmd_games(argc, argv);
         if (c == "mcts") return cmd_mcts(argc, argv);
         if (c == "train") return cmd_train(argc, argv);
+        if (c == "export") return cmd_export(argc, argv);
+        if (c == "convert") return cmd_convert(argc, argv);
     } catch (std::exception& e) {
         fprintf(stderr, "kami_ref: %s\n", e.what());
         return 3;

@@ -16,6 +16,7 @@ def main():
     out_dir = sys.argv[1]
     rank, local_rank, world = kd.env_rank()
     dist = kd.init("gloo")
+    assert kd.collective_device(dist) == "cpu" and kd.collective_device(None) == "cpu"    # tensor placement follows the backend
     start, count = kd.shard(2048 + 3, rank, world)       # BASELINE config 4: 2048 games, uneven tail
     kd.barrier(dist)
     t0 = time.perf_counter()

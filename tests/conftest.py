@@ -38,3 +38,28 @@ def net_fixture(request):
 def observe_fixture():
     z = np.load(os.path.join(GOLDEN, "observe_playouts.npz"), allow_pickle=False)
     return {k: z[k] for k in z.files}
+
+
+# Observed parity maxima of the -m gpu run (max |dlogp|, |dlogit|, |dvalue| per dtype and configuration): collected by
+# the tests through `record_maxima`, written to gpurun_out/parity_maxima.json at session end; the copy kept under
+# profiles/ is what the tolerances in tests/test_gpu_parity.py::TOL are derived from (<= 2x observed).
+_MAXIMA = {}
+
+
+def record_maxima(key, **vals):
+    cur = _MAXIMA.setdefault(key, {})
+    for k, v in vals.items():
+        cur[k] = max(float(v), cur.get(k, 0.0))
+
+
+def pytest_sessionfinish(session, exitstatus):
+    if not _MAXIMA:
+        return
+    import json
+    out = os.path.join(ROOT, "gpurun_out")
+    try:
+        os.makedirs(out, exist_ok=True)
+        with open(os.path.join(out, "parity_maxima.json"), "w") as f:
+            json.dump({k: _MAXIMA[k] for k in sorted(_MAXIMA)}, f, indent=1)
+    except OSError:
+        pass

@@ -5,6 +5,7 @@ import pytest
 
 from kami_amd import NN, KamiError, _lib as L, weights as W
 from oracle import pyoracle as ko
+from conftest import record_maxima
 
 pytestmark = pytest.mark.gpu
 
@@ -15,6 +16,27 @@ TOL = {
     "f16": dict(logp=3e-2, prob_rtol=3e-2, value=2e-3),
     "bf16": dict(logp=2e-1, prob_rtol=2e-1, value=1.5e-2),
 }
+
+
+def compare(key, dtype, got, want, tol=None):
+    """got / want = (policy, value_full, logits or None).  Records the observed maxima under `key` (conftest.record_maxima
+    -> gpurun_out/parity_maxima.json) and asserts them against the stated tolerance of the arithmetic type."""
+    tol = tol or TOL[dtype]
+    p, vf, lg = got
+    op, ovf, olg = want
+    dlogp = float(np.abs(np.log(p) - np.log(op)).max())
+    dval = float(np.abs(vf - ovf).max())
+    big = op > 1e-6
+    drel = float((np.abs(p[big] - op[big]) / op[big]).max()) if big.any() else 0.0
+    vals = dict(logp=dlogp, prob_rel=drel, value=dval)
+    if lg is not None and olg is not None:
+        vals["logit"] = float(np.abs(lg - olg).max())
+    record_maxima(f"{dtype}:{key}", **vals)
+    assert dlogp <= tol["logp"], (key, dtype, vals)
+    assert drel <= tol["prob_rtol"], (key, dtype, vals)
+    assert dval <= tol["value"], (key, dtype, vals)
+    if "logit" in vals:
+        assert vals["logit"] <= tol["logp"], (key, dtype, vals)
 
 
 def make_nn(d, dtype="f32", **kw):
@@ -69,17 +91,12 @@ def test_encode_empty_batch():
 
 # ------------------------------------------------------------------------------ forward
 def check_forward(nn, d, dtype):
-    tol = TOL[dtype]
     policy, vfull, logits = nn.infer_full(d["x"])
     rows = d["policy_rows"]
     assert np.allclose(policy.sum(1), 1.0, atol=1e-3)
-    np.testing.assert_allclose(np.log(policy[rows]), np.log(d["policy"]), atol=tol["logp"], rtol=0)
-    big = d["policy"] > 1e-6
-    np.testing.assert_allclose(policy[rows][big], d["policy"][big], rtol=tol["prob_rtol"])
-    np.testing.assert_allclose(vfull, d["value_full"], atol=tol["value"], rtol=0)
     # logits vs the oracle's logits (the reference does not expose them)
     _, _, ologits = ko.forward(d["blob"], d["features"], d["filters"], d["residuals"], d["x"])
-    np.testing.assert_allclose(logits, ologits, atol=tol["logp"], rtol=0)
+    compare("fixture/" + d["name"], dtype, (policy[rows], vfull, logits[rows]), (d["policy"], d["value_full"], ologits[rows]))
 
 
 def test_forward_f32_vs_reference_fixtures(net_fixture):
@@ -105,11 +122,7 @@ def test_forward_mfma_vs_oracle(dtype, F, C, R, B):
     nn = NN(8, 8, F, 4672, filters=C, residuals=R, dtype=dtype)
     nn.load_weights(blob, 1)
     p, vf, lg = nn.infer_full(x)
-    op, ovf, olg = ko.forward(blob, F, C, R, x)
-    tol = TOL[dtype]
-    np.testing.assert_allclose(lg, olg, atol=tol["logp"], rtol=0)
-    np.testing.assert_allclose(np.log(p), np.log(op), atol=tol["logp"], rtol=0)
-    np.testing.assert_allclose(vf, ovf, atol=tol["value"], rtol=0)
+    compare(f"oracle/F{F}_{R}x{C}_B{B}", dtype, (p, vf, lg), ko.forward(blob, F, C, R, x))
     assert np.allclose(p.sum(1), 1.0, atol=1e-3)
 
 
@@ -168,11 +181,7 @@ def test_forward_wide_nets_vs_oracle(dtype, F, C, R, B):
     nn = NN(8, 8, F, 4672, filters=C, residuals=R, dtype=dtype)
     nn.load_weights(blob, 1)
     p, vf, lg = nn.infer_full(x)
-    op, ovf, olg = ko.forward(blob, F, C, R, x)
-    tol = TOL[dtype]
-    np.testing.assert_allclose(lg, olg, atol=tol["logp"], rtol=0)
-    np.testing.assert_allclose(np.log(p), np.log(op), atol=tol["logp"], rtol=0)
-    np.testing.assert_allclose(vf, ovf, atol=tol["value"], rtol=0)
+    compare(f"oracle-wide/F{F}_{R}x{C}_B{B}", dtype, (p, vf, lg), ko.forward(blob, F, C, R, x))
     # NaN guard on this path too
     xb = x.copy(); xb[B - 1, 0, 0, 0] = np.nan
     with pytest.raises(KamiError) as ei:
@@ -238,10 +247,7 @@ def test_forward_f32_vs_oracle_bigger_nets(F, C, R, B):
     nn = NN(8, 8, F, 4672, filters=C, residuals=R, dtype="f32")
     nn.load_weights(blob, 1)
     p, vf, lg = nn.infer_full(x)
-    op, ovf, olg = ko.forward(blob, F, C, R, x)
-    np.testing.assert_allclose(lg, olg, atol=TOL["f32"]["logp"], rtol=0)
-    np.testing.assert_allclose(np.log(p), np.log(op), atol=TOL["f32"]["logp"], rtol=0)
-    np.testing.assert_allclose(vf, ovf, atol=TOL["f32"]["value"], rtol=0)
+    compare(f"oracle/F{F}_{R}x{C}_B{B}", "f32", (p, vf, lg), ko.forward(blob, F, C, R, x))
 
 
 def test_batch_sizes_and_row_independence():
@@ -416,6 +422,52 @@ def test_bench_two_ranks_control_flow(tmp_path):
     assert "cpu_baseline" not in d and d["roofline"]["bound"] == "mfma"
 
 
+def _run_rccl_worker(tmp_path, nproc):
+    import json, os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    port = 29300 + os.getpid() % 1000
+    worker = os.path.join(root, "tests", "_rccl_worker.py")
+    env = dict(os.environ, OMP_NUM_THREADS="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    if nproc == 1:
+        env.update(RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        cmd = [sys.executable, worker, str(tmp_path)]
+    else:
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={nproc}",
+               "--master-addr", "127.0.0.1", "--master-port", str(port), worker, str(tmp_path)]
+    r = subprocess.run(cmd, timeout=600, env=env, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-3000:]
+    return [json.load(open(tmp_path / f"rank{k}.json")) for k in range(nproc)]
+
+
+def test_rccl_backend_single_rank_group(tmp_path):
+    """The collectives of rows f3 / (e) through the PRODUCTION backend ("nccl" = RCCL) on this box's one GPU: a world of
+    one rank is still an RCCL communicator, and it is where a host tensor handed to the backend fails.  The helpers
+    place their tensors by the group's backend (kami_amd.dist.collective_device)."""
+    from kami_amd import weights as W
+    res = _run_rccl_worker(tmp_path, 1)[0]
+    ref = W.random_weights(30, 8, 1, seed=77)
+    assert res["backend"].lower() == "nccl" and res["world"] == 1
+    assert abs(res["dt_max"] - 0.05) < 1e-12
+    assert res["inserted"] == 0 and res["total"] == 3                     # nothing to merge from a peer, own records kept
+    assert res["compact"] == [list(range(0, 8))]
+    assert res["wgen"] == 41 and res["wn"] == ref.size and abs(res["wsum"] - float(ref.astype(np.float64).sum())) < 1e-9
+
+
+def test_rccl_backend_two_ranks(tmp_path):
+    """Same worker, one rank per GPU over RCCL / xGMI — runs where the box has >= 2 GPUs (the driver's 8-GPU node),
+    skips on the one-GPU box: replay merge rank-major into the root, weight broadcast, max over ranks."""
+    import torch
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs >= 2 GPUs")
+    from kami_amd import weights as W
+    res = _run_rccl_worker(tmp_path, 2)
+    ref = W.random_weights(30, 8, 1, seed=77)
+    assert all(abs(r["dt_max"] - 0.10) < 1e-12 for r in res)
+    assert res[0]["inserted"] == 4 and res[0]["total"] == 7 and res[1]["inserted"] == 0
+    assert res[0]["compact"] == [list(range(0, 8)), list(range(10, 22))] and res[1]["compact"] == []
+    assert all(r["wgen"] == 41 and abs(r["wsum"] - float(ref.astype(np.float64).sum())) < 1e-9 for r in res)
+
+
 def test_reference_programs_on_the_cpp_mirror(tmp_path):
     """The reference's OWN test/nndisk.cpp, compiled unmodified against kami_amd/host/nn.h and
     libkamihip.so (make -C kami_amd/host dropin; binary under oracle/_ref/dropin, built in the build
@@ -498,6 +550,40 @@ def test_reference_kami_program_full_cycle_on_the_cpp_mirror(tmp_path, program):
         assert "[White \"KAMI generation" in out and (" 1-0 {" in out or " 0-1 {" in out or " 1/2-1/2 {" in out)
 
 
+@pytest.mark.parametrize("program", ["kami", "kami_native"])
+def test_configs0_literal_one_game_64_sims(tmp_path, program):
+    """BASELINE configs[0] literally — 1 self-play game, 64 MCTS sims per move (test/selfplay.cpp's path: one inference
+    thread, selfplay_batch 1, selfplay_nodes 64, the 2x64 default net of options.def.yml) — with the engine as the
+    evaluator: the reference's own program on the C++ mirror (`kami`), and the same kami.cpp on this repository's
+    host side (`kami_native`).  It plays whole games of batch-1 evaluations and fills its replay buffer; the model
+    it boots from (`model_path`, kami.cpp:39-51) is a checkpoint in the REFERENCE's format (tests/golden, written by the
+    reference's NN::write), so the literal shape also exercises NN::read on a torch archive."""
+    import os, re, shutil, subprocess, time, threading
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(root, "oracle", "_ref", "dropin", program)
+    if not os.path.exists(exe):
+        pytest.skip("drop-in binaries not built (needs the reference tree at build time)")
+    shutil.copy(os.path.join(root, "tests", "golden", "ref_checkpoint_f30_c8_r1.pt"), tmp_path / "ref.pt")
+    opts = dict(filters=8, residuals=1, selfplay_batch=1, selfplay_nodes=64, inference_threads=1, training_threads=0,
+                replaybuffer_size=4096, model_path=str(tmp_path / "ref.pt"), engine_dtype="bf16")
+    (tmp_path / "options.yml").write_text("".join(f"{k}: {v}\n" for k, v in opts.items()))
+    proc = subprocess.Popen([exe], cwd=tmp_path, stdin=subprocess.PIPE, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    lines = []
+    t = threading.Thread(target=lambda: lines.extend(iter(proc.stdout.readline, "")), daemon=True)
+    t.start()
+    try:
+        time.sleep(12.0)
+        proc.stdin.write("status\nquit\n"); proc.stdin.flush()
+        proc.wait(timeout=60)
+    except Exception:
+        proc.kill()
+    out = "".join(lines)
+    assert "Current generation: 7" in out, out[-2000:]          # the archive's generation IValue (nn.cpp:196)
+    m = re.search(r"Total experiences: (\d+)", out)
+    assert m and int(m.group(1)) >= 20, out[-2000:]             # finished games reached the replay buffer
+    assert "Error in command" not in out, out[-2000:]
+
+
 # ------------------------------------------------------------------------------ full-size properties
 def test_full_size_properties_headline_config():
     """BASELINE configs[1] at its full size (512 x 119x8x8, 6x64), where the oracle is too slow to
@@ -523,13 +609,106 @@ def test_full_size_properties_headline_config():
         assert np.array_equal(p3, p[perm]) and np.array_equal(vf3, vf[perm])
     # cross-precision agreement within the stated tolerances (f32 = exact MFMA path as the anchor)
     for dtype in ("bf16", "f16"):
-        np.testing.assert_allclose(np.log(out[dtype][0]), np.log(out["f32"][0]), atol=TOL[dtype]["logp"], rtol=0)
-        np.testing.assert_allclose(out[dtype][1], out["f32"][1], atol=TOL[dtype]["value"], rtol=0)
+        compare("full/configs1_6x64_B512_vs_f32mfma", dtype, (out[dtype][0], out[dtype][1], None), (out["f32"][0], out["f32"][1], None))
     # and a sample of rows against the oracle
     rows = [0, 1, 255, 256, 511]
     op, ovf, _ = ko.forward(blob, F, C, R, x[rows])
-    np.testing.assert_allclose(np.log(out["f32"][0][rows]), np.log(op), atol=TOL["f32"]["logp"], rtol=0)
-    np.testing.assert_allclose(out["f32"][1][rows], ovf, atol=TOL["f32"]["value"], rtol=0)
+    for dtype in ("f32", "bf16", "f16"):
+        compare("full/configs1_6x64_B512_rows_vs_oracle", dtype, (out[dtype][0][rows], out[dtype][1][rows], None), (op, ovf, None))
+
+
+FULL_DEPTH = [
+    # BASELINE configs[2]: 10 blocks x 128 filters, batch 1024, bf16
+    ("configs2_10x128_B1024", "bf16", 119, 128, 10, 1024),
+    # BASELINE configs[4]: 20 blocks x 256 filters, fp16, batch 2048 (and the batch 256 the bench variant times)
+    ("configs4_20x256_B256", "f16", 119, 256, 20, 256),
+    ("configs4_20x256_B2048", "f16", 119, 256, 20, 2048),
+    # the other precision of each, at a batch the per-layer kernels' variants all see
+    ("configs2_10x128_B1024", "f16", 119, 128, 10, 1024),
+    ("configs4_20x256_B256", "bf16", 119, 256, 20, 256),
+]
+
+
+@pytest.mark.parametrize("name,dtype,F,C,R,B", FULL_DEPTH, ids=[f"{n}-{d}" for n, d, *_ in FULL_DEPTH])
+def test_full_size_properties_wide_configs(name, dtype, F, C, R, B):
+    """BASELINE configs[2] and configs[4] at their FULL depth and batch (nn.cpp:26-34,59-91): low-precision error
+    grows with depth, so the wide nets are pinned where it is largest.  Size-independent properties on the whole
+    batch; rows 0 / 1 / middle / last against the CPU oracle (4 evaluations of a 0.4 / 3.1 GFLOP net: cheap);
+    cross-check of the same rows against the engine's exact-fp32 path."""
+    blob = W.random_weights(F, C, R, seed=1000 + C + R, peaky=20.0)
+    x = np.random.default_rng(B + C).random((B, 8, 8, F), dtype=np.float32)
+    nn = NN(8, 8, F, 4672, filters=C, residuals=R, dtype=dtype)
+    nn.load_weights(blob, 1)
+    p, vf, lg = nn.infer_full(x)
+    assert np.isfinite(p).all() and (p >= 0).all() and np.isfinite(lg).all()
+    np.testing.assert_allclose(p.sum(1, dtype=np.float64), 1.0, atol=2e-5)           # softmax rows
+    assert np.abs(vf).max() <= 1.0                                                   # tanh range
+    # batching invariance: the second half evaluated alone gives the same bits (another workgroup schedule)
+    h = B // 2
+    p2, vf2, lg2 = nn.infer_full(x[h:])
+    assert np.array_equal(p2, p[h:]) and np.array_equal(vf2, vf[h:]) and np.array_equal(lg2, lg[h:])
+    # permutation equivariance: rows follow their inputs
+    perm = np.random.default_rng(2).permutation(B)
+    p3, vf3, _ = nn.infer_full(x[perm], want_logits=False)
+    assert np.array_equal(p3, p[perm]) and np.array_equal(vf3, vf[perm])
+    # rows against the oracle (fp32 CPU restatement of the reference, pinned by the reference's fixtures)
+    rows = [0, 1, B // 2 - 1, B // 2, B - 1]
+    want = ko.forward(blob, F, C, R, x[rows])
+    compare(f"full/{name}_rows_vs_oracle", dtype, (p[rows], vf[rows], lg[rows]), want)
+    # and the engine's exact-fp32 arithmetic on 64 rows (fp32 MFMA path up to 128 filters, fp32 VALU kernels beyond)
+    sub = np.linspace(0, B - 1, 64).astype(int)
+    nf = NN(8, 8, F, 4672, filters=C, residuals=R, dtype="f32")
+    nf.load_weights(blob, 1)
+    fp, fvf, flg = nf.infer_full(x[sub])
+    compare(f"full/{name}_rows_vs_oracle", "f32", (fp[:2], fvf[:2], flg[:2]), tuple(w[:2] for w in want))
+    compare(f"full/{name}_64rows_vs_f32", dtype, (p[sub], vf[sub], lg[sub]), (fp, fvf, flg))
+
+
+def test_selfplay_pool_literal_configs1_shape():
+    """BASELINE configs[1] literally: 256 parallel games, 800 visits per move, batch-512 evaluations (two leaves of
+    every tree in flight), 6-block x 64-filter net.  A few seconds of play: the pool runs at that shape, its batches
+    ARE 512 wide, moves need 800 visits, records come out well-formed."""
+    from kami_amd import search as S
+    F, C, R = 30, 64, 6
+    nn = NN(8, 8, F, 4672, filters=C, residuals=R, dtype="bf16", value_mode=L.KH_VALUE_PER_SAMPLE0)
+    nn.load_weights(W.random_weights(F, C, R, seed=5, peaky=5.0), 1)
+    pool = S.Pool(nn, games=256, threads=1, nodes=800, leaves_per_tree=2, seed=11)
+    st = pool.run(min_evals=600000, max_seconds=8.0)
+    assert st.evals >= 256 * 800, st.evals                      # every game got past its first move's budget
+    assert st.mean_batch >= 480, st.mean_batch                  # batch-512 evaluations (terminal leaves cost nothing)
+    assert st.moves >= 256 and st.moves <= st.evals // 700 + 256 * 2
+    for r in pool.drain()[:100]:
+        v = np.array(r.visits[:r.nact])
+        assert 0 < r.nact <= S.MAX_RECORD_ACTIONS and abs(v.sum() - 1.0) < 1e-3
+
+
+def test_reference_checkpoint_ingest(tmp_path):
+    """A checkpoint written by the reference's own NN::write (tests/golden/ref_checkpoint_f30_c8_r1.pt, generated from
+    the blob of the net_f30_c8_r1 fixture): NN::read takes it (kh_load_checkpoint: zip + pickle walk, no libtorch), the
+    generation follows, and the forward pass equals the reference's own outputs for that network."""
+    import os
+    from conftest import GOLDEN, load_net_fixture
+    d = load_net_fixture(os.path.join(GOLDEN, "net_f30_c8_r1.npz"))
+    ck = os.path.join(GOLDEN, "ref_checkpoint_f30_c8_r1.pt")
+    for dtype in ("f32", "bf16"):
+        nn = NN(8, 8, 30, 4672, filters=8, residuals=1, dtype=dtype)
+        nn.read(ck)
+        assert nn.get_generation() == 7
+        check_forward(nn, d, dtype)
+    # the C entry point in one call, and its shape check
+    nn = NN(8, 8, 30, 4672, filters=8, residuals=1)
+    assert nn._lib.kh_load_checkpoint(nn.handle, ck.encode()) == L.KH_OK and nn.get_generation() == 7
+    p1, v1 = nn.infer(d["x"])
+    np.testing.assert_allclose(v1, d["value"], atol=TOL["f32"]["value"], rtol=0)
+    other = NN(8, 8, 30, 4672, filters=16, residuals=1)
+    assert other._lib.kh_load_checkpoint(other.handle, ck.encode()) == L.KH_ERR_INVALID
+    # write() -> read() of the engine's own container still round-trips after an archive ingest
+    path = str(tmp_path / "m.bin")
+    nn.write(path)
+    twin = NN(8, 8, 30, 4672, filters=8, residuals=1)
+    twin.read(path)
+    p2, v2 = twin.infer(d["x"])
+    assert twin.get_generation() == 7 and np.array_equal(p1, p2) and np.array_equal(v1, v2)
 
 
 def test_encode_full_size_properties():

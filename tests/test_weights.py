@@ -29,3 +29,68 @@ def test_random_weights_deterministic():
     b = W.random_weights(30, 8, 1, seed=3)
     assert np.array_equal(a, b)
     assert not np.array_equal(a, W.random_weights(30, 8, 1, seed=4))
+
+
+# ---------------------------------------------------------------------------------------------
+# reference checkpoints (NN::write, nn.cpp:189-202): a libtorch archive read without libtorch
+
+import os
+import shutil
+import zipfile
+
+import pytest
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+CKPT = os.path.join(GOLDEN, "ref_checkpoint_f30_c8_r1.pt")
+
+
+def test_reference_checkpoint_both_readers_match_the_fixture_blob():
+    """tests/golden/ref_checkpoint_f30_c8_r1.pt was written by the reference's own NN::write from the blob of
+    the net_f30_c8_r1 fixture (oracle/gen_golden.py::gen_checkpoint).  The engine's C reader
+    (kh_checkpoint_read, csrc/torch_archive.h) and the Python twin must both give that blob back bit for bit."""
+    from kami_amd import torch_archive as TA
+    from kami_amd.nn import read_checkpoint
+    want = np.load(os.path.join(GOLDEN, "net_f30_c8_r1.npz"))["blob"]
+    for reader in (read_checkpoint, TA.load_reference_checkpoint):
+        blob, F, C, R, gen = reader(CKPT)
+        assert (F, C, R, gen) == (30, 8, 1, 7)
+        assert blob.dtype == np.float32 and np.array_equal(blob.view(np.uint32), want.view(np.uint32))
+    tensors, attrs = TA.read_archive(CKPT)
+    assert attrs["generation"] == 7 and tensors["batchnorm1.num_batches_tracked"].dtype == np.int64
+    assert tensors["residual0.conv2.weight"].shape == (8, 8, 3, 3)
+
+
+def test_checkpoint_reader_takes_the_engine_container_too(tmp_path):
+    from kami_amd.nn import read_checkpoint
+    blob = W.random_weights(30, 8, 2, seed=5)
+    p = str(tmp_path / "w.bin")
+    W.save(p, blob, 30, 8, 2, generation=4)
+    b2, F, C, R, gen = read_checkpoint(p)
+    assert (F, C, R, gen) == (30, 8, 2, 4) and np.array_equal(blob, b2)
+
+
+def test_checkpoint_reader_refuses_what_it_does_not_know(tmp_path):
+    """Not a checkpoint, a truncated archive, and an archive whose pickle asks for a call outside the two
+    reconstructors libtorch's module pickler emits: all fail with an error, nothing is executed."""
+    from kami_amd import KamiError, torch_archive as TA
+    from kami_amd.nn import read_checkpoint
+    junk = tmp_path / "junk.bin"
+    junk.write_bytes(b"hello, not a checkpoint at all" * 10)
+    with pytest.raises(KamiError):
+        read_checkpoint(str(junk))
+    cut = tmp_path / "cut.pt"
+    cut.write_bytes(open(CKPT, "rb").read()[:50000])
+    with pytest.raises(KamiError):
+        read_checkpoint(str(cut))
+    # same members, but data.pkl replaced by a pickle that REDUCEs os.system
+    evil = tmp_path / "evil.pt"
+    with zipfile.ZipFile(CKPT) as zin, zipfile.ZipFile(evil, "w", zipfile.ZIP_STORED) as zout:
+        for item in zin.infolist():
+            data = zin.read(item.filename)
+            if item.filename.endswith("/data.pkl"):
+                data = b"\x80\x02cos\nsystem\nX\x04\x00\x00\x00true\x85R."
+            zout.writestr(item.filename, data)
+    with pytest.raises(KamiError, match="refusing to call os.system"):
+        read_checkpoint(str(evil))
+    with pytest.raises(TA.ArchiveError, match="refusing to call"):
+        TA.load_reference_checkpoint(str(evil))
