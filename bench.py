@@ -3,18 +3,32 @@
 
 A "step" is one pass of the hot path (stem conv + residual tower + policy/value heads,
 kami/nn/nn.cpp:59-91) over one synthetic batch of 512 x (119 x 8 x 8) planes already resident
-in HBM.  N > 1: one process per GPU (torch.distributed / RCCL only for the barrier and the
-max-over-ranks), every rank evaluates its own disjoint batch: weak scaling, no data-path
-collective (leaf evaluations are independent).
+in HBM (BASELINE configs[1]).  N > 1: one process per GPU (torch.distributed / RCCL only for the
+barrier and the max-over-ranks), every rank evaluates its own disjoint batch: weak scaling, no
+data-path collective (leaf evaluations are independent).
 
     python bench.py [--gpus N --steps K --warmup W] [--dtype bf16|f16|f32] [--batch 512]
+
+The ONE JSON line carries, besides the contract's fields:
+  roofline      the dominant kernel's achieved TFLOP/s (HIP events on the stream it runs on) vs the dense MFMA peak
+  distribution  p10 / median / p90 of >= 50 separately timed repeats of the same step
+  variants      (N = 1) the other legs SURVEY §8d / BASELINE.md §4 define, each with its own workload label and roofline:
+                exact fp32, f16, F=30 with the encoder fused into the kernel, configs[2] (10x128, batch 1024, bf16),
+                configs[4]'s net on one GPU (20x256, f16, batch 256)
+  end_to_end    (N = 1) what a caller of the host-buffer ABI sees, PCIe included: kh_infer (the legacy float ABI of
+                NN::infer) from 1 and 4 threads, kh_encode_infer_legal (compact records in, legal priors out)
+  cpu_baseline  (N = 1) the unmodified reference's NN::infer on this box's host cores, bounded sample
+`value` is always the configs[1] kernel-path number; nothing in variants / end_to_end replaces it.
 """
 import argparse
 import ctypes as C
+import glob
+import hashlib
 import json
 import os
 import subprocess
 import sys
+import threading
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
@@ -56,7 +70,8 @@ def cpu_baseline(F, Cc, R, batch):
     ko.forward(blob, F, Cc, R, x, want_logits=False)
     dt = time.perf_counter() - t0
     return {"value": round(n / dt, 1), "unit": "leaf-evals/s", "cores": ko.lib().ko_max_threads(),
-            "kind": "port", "sample": f"one oracle forward over {n} boards of 8x8x{F}, {R}x{Cc} net (OpenMP)"}
+            "kind": "port", "sample": f"one oracle forward over {n} boards of 8x8x{F}, {R}x{Cc} net (OpenMP); "
+                                      "oracle/_ref/kami_ref (the reference build) was not present"}
 
 
 def baseline_metric():
@@ -64,25 +79,203 @@ def baseline_metric():
     try:
         return json.load(open(os.path.join(ROOT, "BASELINE.json")))["metric"]
     except Exception:
-        return "NN leaf-evals/sec at batch 512 (119\u00d78\u00d78 planes), 1/2/4/8 MI355X"
+        return "NN leaf-evals/sec at batch 512 (119×8×8 planes), 1/2/4/8 MI355X"
+
+
+def kernel_source_sha():
+    """sha-256 (first 16 hex digits) over the kernel sources: a PMC summary under profiles/ only speaks for the
+    kernels it was collected on."""
+    h = hashlib.sha256()
+    for f in sorted(glob.glob(os.path.join(ROOT, "kami_amd", "csrc", "*.hip")) + glob.glob(os.path.join(ROOT, "kami_amd", "csrc", "*.h"))):
+        h.update(open(f, "rb").read())
+    return h.hexdigest()[:16]
 
 
 def measured_traffic(F, Cc, R, B, dtype):
-    """HBM bytes per launch of the forward kernel from the PMC passes kept under profiles/
-    (FETCH_SIZE / WRITE_SIZE, separate rocprofv3 --pmc runs, gfx950 corrections applied as
-    MI355X_MICROARCH.md prescribes).  Counters cannot be read from inside this process, so this
-    is the committed measurement of the SAME command; None when the workload differs."""
-    import glob
-    best = None
+    """HBM bytes per launch of the forward kernel from the PMC passes kept under profiles/ (FETCH_SIZE / WRITE_SIZE,
+    separate rocprofv3 --pmc runs, gfx950 corrections applied as MI355X_MICROARCH.md prescribes).  Counters cannot be
+    read from inside this process, so this is the committed measurement of the SAME command: (bytes, source) where
+    source names the file and says whether the kernels are still the ones it was collected on; (None, None) when no
+    summary matches the workload, and bytes None when the kernel sources have changed since."""
+    best = (None, None)
+    sha = kernel_source_sha()
     for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_summary.json"))):
         try:
             d = json.load(open(path))
         except Exception:
             continue
         w = d.get("workload_key", {})
-        if w == {"features": F, "filters": Cc, "residuals": R, "batch": B, "dtype": dtype}:
-            best = d["hbm_traffic"]["total_bytes_per_launch"]
+        if w == {"features": F, "filters": Cc, "residuals": R, "batch": B, "dtype": dtype} and "hbm_traffic" in d:
+            same = d.get("kernel_source_sha16") == sha
+            src = {"file": os.path.relpath(path, ROOT), "kernel_source_sha16": d.get("kernel_source_sha16"),
+                   "current_kernel_source_sha16": sha, "same_kernels": same}
+            best = (d["hbm_traffic"]["total_bytes_per_launch"] if same else None, src)
     return best
+
+
+def workload_label(B, F, R, Cc):
+    names = {(512, 119, 6, 64): "BASELINE configs[1]", (1024, 119, 10, 128): "BASELINE configs[2]",
+             (2048, 119, 20, 256): "BASELINE configs[4] per GPU"}
+    tag = names.get((B, F, R, Cc), "not a BASELINE configuration as such")
+    return (f"{B} random boards x ({F}x8x8) planes per GPU, {R}-block x {Cc}-filter net, "
+            f"batched leaf evaluate() forward ({tag})")
+
+
+def metric_label(B, F):
+    base = baseline_metric()
+    if (B, F) == (512, 119):
+        return base
+    return f"NN leaf-evals/sec at batch {B} ({F}×8×8 planes), MI355X"
+
+
+class DeviceLeg:
+    """One engine + device-resident synthetic inputs; timed through kh_time_infer_device (HIP events on the
+    engine's own stream, the stream the kernels run on)."""
+
+    def __init__(self, torch, lib, NN, W, dtype, F, Cc, R, B, seed, device):
+        self.lib, self.B, self.F, self.Cc, self.R, self.dtype = lib, B, F, Cc, R, dtype
+        self.nn = NN(8, 8, F, 4672, filters=Cc, residuals=R, dtype=dtype, device=device)
+        self.nn.load_weights(W.random_weights(F, Cc, R, seed=20240607), 1)
+        g = torch.Generator(device="cuda")
+        g.manual_seed(seed)
+        self.x = torch.rand((B, 8, 8, F), generator=g, device="cuda", dtype=torch.float32)   # test/nn.cpp:23-24 convention
+        self.policy = torch.empty((B, 4672), device="cuda", dtype=torch.float32)
+        self.vfull = torch.empty((B, 256), device="cuda", dtype=torch.float32)
+        torch.cuda.synchronize()                 # inputs complete before any engine stream touches them
+        self.flops = W.flops_per_eval(F, Cc, R) * B
+
+    def time_ms(self, iters):
+        ms = C.c_float(0)
+        rc = self.lib.kh_time_infer_device(self.nn.handle, C.c_void_p(self.x.data_ptr()), self.B, C.c_void_p(self.policy.data_ptr()),
+                                           C.c_void_p(self.vfull.data_ptr()), iters, C.byref(ms))
+        if rc:
+            from kami_amd import _lib as L
+            raise RuntimeError(L.last_error())
+        return ms.value
+
+    def settled_ms(self, prewarm, seconds):
+        """prewarm seconds of untimed load (clock ramp), then launches for about `seconds`, averaged."""
+        t0 = time.perf_counter()
+        ms = self.time_ms(20)
+        while time.perf_counter() - t0 < prewarm:
+            ms = self.time_ms(max(20, int(0.05 / max(ms, 1e-3) * 1e3)))
+        iters = max(20, int(seconds / (ms * 1e-3)))
+        return self.time_ms(iters), iters
+
+    def roofline(self, ms):
+        achieved = self.flops / (ms * 1e-3) / 1e12
+        peak = PEAK_TFLOPS[self.dtype]
+        return {"bound": "mfma", "achieved": round(achieved, 3), "peak": peak, "unit": "TFLOP/s", "frac": round(achieved / peak, 5),
+                "kernel_ms": round(ms, 5), "flops_per_launch": self.flops}
+
+
+def variant_legs(torch, lib, NN, W, L, device, prewarm):
+    import numpy as np
+    out = []
+    specs = [("f32", 119, 64, 6, 512, "exact fp32 on v_mfma_f32_32x32x2_f32 (the reference's own precision)"),
+             ("f16", 119, 64, 6, 512, "f16 operands, fp32 accumulate"),
+             ("bf16", 119, 128, 10, 1024, "per-layer MFMA kernels (layers_mfma.hip)"),
+             ("f16", 119, 256, 20, 256, "per-layer MFMA kernels (layers_mfma.hip); configs[4]'s net at a batch one launch round covers")]
+    for dtype, F, Cc, R, B, note in specs:
+        leg = DeviceLeg(torch, lib, NN, W, dtype, F, Cc, R, B, 7, device)
+        ms, iters = leg.settled_ms(prewarm, 0.4)
+        out.append({"workload": workload_label(B, F, R, Cc), "note": note, "dtype": dtype, "value": round(B / (ms * 1e-3), 1),
+                    "unit": "leaf-evals/s", "ms_per_step": round(ms, 5), "launches_timed": iters, "roofline": leg.roofline(ms)})
+        del leg
+        torch.cuda.empty_cache()
+    # F = 30 (the reference encoder's planes) with compact ingest: 80-byte records in, Env::observe inside the kernel
+    B, F, Cc, R = 512, 30, 64, 6
+    nn = NN(8, 8, F, 4672, filters=Cc, residuals=R, dtype="bf16", device=device)
+    nn.load_weights(W.random_weights(F, Cc, R, seed=20240607), 1)
+    rng = np.random.default_rng(0)
+    boards = np.zeros(B, dtype=L.BOARD_DTYPE)
+    boards["piece_occ"] = rng.integers(0, 2**63, (B, 6), dtype=np.uint64)
+    boards["color_occ"] = rng.integers(0, 2**63, (B, 2), dtype=np.uint64)
+    boards["ply"] = rng.integers(0, 300, B); boards["ctm"] = rng.integers(0, 2, B); boards["castle_rights"] = rng.integers(0, 16, B)
+    d_b = torch.from_numpy(boards.view(np.uint8).reshape(B, 80)).cuda()
+    pol = torch.empty((B, 4672), device="cuda"); vf = torch.empty((B, 256), device="cuda")
+    st = torch.cuda.Stream()
+    sp = C.c_void_p(st.cuda_stream)
+    torch.cuda.synchronize()
+
+    def run(n):
+        for _ in range(n):
+            if lib.kh_encode_infer_device(nn.handle, C.c_void_p(d_b.data_ptr()), B, C.c_void_p(pol.data_ptr()), C.c_void_p(vf.data_ptr()), sp):
+                raise RuntimeError(L.last_error())
+    t0 = time.perf_counter()
+    while time.perf_counter() - t0 < prewarm:
+        run(200); st.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    K = 4000
+    e0.record(st); run(K); e1.record(st); st.synchronize()
+    ms = e0.elapsed_time(e1) / K
+    flops = W.flops_per_eval(F, Cc, R) * B
+    out.append({"workload": f"{B} compact board records (80 B each) per GPU, Env::observe fused into the forward kernel (F = 30 planes), "
+                            f"{R}-block x {Cc}-filter net (kh_encode_infer_device; SURVEY 8f row 1)",
+                "dtype": "bf16", "value": round(B / (ms * 1e-3), 1), "unit": "leaf-evals/s", "ms_per_step": round(ms, 5), "launches_timed": K,
+                "roofline": {"bound": "mfma", "achieved": round(flops / (ms * 1e-3) / 1e12, 3), "peak": 2500.0, "unit": "TFLOP/s",
+                             "frac": round(flops / (ms * 1e-3) / 1e12 / 2500.0, 5), "kernel_ms": round(ms, 5), "flops_per_launch": flops}})
+    return out
+
+
+def end_to_end_legs(NN, W, L, device):
+    """The host-buffer ABI, PCIe included (what an unmodified kami sees through NN::infer, and what this repository's
+    search sends): pageable caller buffers, synchronous calls, evaluations per wall second."""
+    import numpy as np
+    out = []
+
+    def rate(fn, n, seconds=0.8):
+        fn(); fn()
+        t0 = time.perf_counter(); k = 0
+        while time.perf_counter() - t0 < seconds:
+            fn(); k += 1
+        return n * k / (time.perf_counter() - t0)
+
+    def threaded(make_fn, n, T):
+        res = [0.0] * T
+        start = threading.Barrier(T)
+
+        def work(i):
+            fn = make_fn(i)
+            fn(); start.wait()
+            res[i] = rate(fn, n)
+        th = [threading.Thread(target=work, args=(i,)) for i in range(T)]
+        [t.start() for t in th]; [t.join() for t in th]
+        return sum(res)
+
+    B, F = 512, 119
+    nn = NN(8, 8, F, 4672, filters=64, residuals=6, dtype="bf16", device=device)
+    nn.load_weights(W.random_weights(F, 64, 6, seed=1), 1)
+
+    def make_infer(i):
+        x = np.random.default_rng(i).random((B, 8, 8, F), dtype=np.float32)
+        pol = np.empty((B, 4672), np.float32); val = np.empty(B, np.float32)
+        return lambda: nn.infer(x, B, pol, val)
+    for T in (1, 4):
+        out.append({"call": "kh_infer", "workload": f"{B} x ({F}x8x8) fp32 planes in, full [4672] policy + value out per call, 6x64 bf16 "
+                                                    "(the legacy float ABI of NN::infer, nn.cpp:155-187)",
+                    "threads": T, "value": round(threaded(make_infer, B, T), 1), "unit": "leaf-evals/s",
+                    "pcie_bound": "2.07 M/s at 63 GB/s per direction (30 464 B in, 18 692 B out per evaluation; SURVEY 7)"})
+    del nn
+    F = 30
+    nn = NN(8, 8, F, 4672, filters=64, residuals=6, dtype="bf16", device=device, value_mode=L.KH_VALUE_PER_SAMPLE0)
+    nn.load_weights(W.random_weights(F, 64, 6, seed=1), 1)
+
+    def make_legal(i):
+        rng = np.random.default_rng(i)
+        boards = np.zeros(B, dtype=L.BOARD_DTYPE)
+        boards["piece_occ"] = rng.integers(0, 2**63, (B, 6), dtype=np.uint64)
+        boards["color_occ"] = rng.integers(0, 2**63, (B, 2), dtype=np.uint64)
+        boards["ply"] = rng.integers(0, 300, B); boards["ctm"] = rng.integers(0, 2, B)
+        nact = rng.integers(10, 50, B)
+        offs = np.concatenate([[0], np.cumsum(nact)]).astype(np.int32)
+        acts = rng.integers(0, 4672, int(offs[-1])).astype(np.int32)
+        return lambda: nn.infer_legal(boards, offs, acts)
+    for T in (1, 4):
+        out.append({"call": "kh_encode_infer_legal", "workload": f"{B} compact records (80 B) + ~30 legal actions each in, legal priors + value out, "
+                                                                 "6x64 bf16, encoder and legal-move gather on the device (SURVEY 8f row 1)",
+                    "threads": T, "value": round(threaded(make_legal, B, T), 1), "unit": "leaf-evals/s"})
+    return out
 
 
 def main():
@@ -96,9 +289,12 @@ def main():
     ap.add_argument("--features", type=int, default=119)
     ap.add_argument("--filters", type=int, default=64)
     ap.add_argument("--residuals", type=int, default=6)
+    ap.add_argument("--repeats", type=int, default=60, help="separately timed repeats for p10 / median / p90")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-variants", action="store_true", help="skip the variants / end_to_end legs (N = 1 only anyway)")
     a = ap.parse_args()
 
+    import numpy as np
     import torch
     from kami_amd import NN, weights as W, _lib as L, dist as kd
 
@@ -109,21 +305,16 @@ def main():
     # one GPU to rehearse the N > 1 control flow on a single-GPU box (RCCL refuses duplicate devices)
     backend = os.environ.get("KAMI_DIST_BACKEND", "nccl")
     dev_index = local_rank % max(1, torch.cuda.device_count())
-    local_rank = dev_index
     torch.cuda.set_device(dev_index)
     dist = kd.init(backend)         # RCCL; only the barrier and the max-over-ranks use it
 
     F, Cc, R, B = a.features, a.filters, a.residuals, a.batch
-    nn = NN(8, 8, F, 4672, filters=Cc, residuals=R, dtype=a.dtype, device=local_rank)
-    nn.load_weights(W.random_weights(F, Cc, R, seed=20240607), 1)
     lib = L.load()
-
-    g = torch.Generator(device="cuda")
-    g.manual_seed(20240607 + rank)
-    x = torch.rand((B, 8, 8, F), generator=g, device="cuda", dtype=torch.float32)   # test/nn.cpp:23-24 convention
-    policy = torch.empty((B, 4672), device="cuda", dtype=torch.float32)
-    vfull = torch.empty((B, 256), device="cuda", dtype=torch.float32)
-    stream = torch.cuda.current_stream()
+    leg = DeviceLeg(torch, lib, NN, W, a.dtype, F, Cc, R, B, 20240607 + rank, dev_index)
+    nn, x, policy, vfull = leg.nn, leg.x, leg.policy, leg.vfull
+    # an explicit stream of our own: torch's current stream is the legacy default stream (handle 0), which the
+    # engine would read as "use your own stream"
+    stream = torch.cuda.Stream()
     sp = C.c_void_p(stream.cuda_stream)
 
     def step():
@@ -157,40 +348,50 @@ def main():
     dt = kd.max_over_ranks(dist, dt)
     assert bool(torch.isfinite(policy).all()) and abs(float(policy[0].sum()) - 1.0) < 1e-2
 
+    # distribution: `repeats` separately synchronised bursts of the same step (after the timed region: a sync per
+    # burst would perturb `value`), each long enough (>= 2 ms) that the synchronise does not dominate
+    per = max(1, min(a.steps, max(20, int(2.0 / max(dt / a.steps * 1e3, 1e-3)))))
+    for _ in range(a.warmup):
+        step()
+    torch.cuda.synchronize()
+    rates = []
+    for _ in range(max(1, a.repeats)):
+        t1 = time.perf_counter()
+        for _ in range(per):
+            step()
+        torch.cuda.synchronize()
+        rates.append(B * per / (time.perf_counter() - t1))
+    rates.sort()
+    pct = lambda q: rates[min(len(rates) - 1, int(round(q * (len(rates) - 1))))]
+
     # roofline of the dominant kernel (the forward pass), HIP events on the engine's own stream
-    ms = C.c_float(0)
-    iters = max(200, min(a.steps, 2000))
-    t_pw = time.perf_counter()
-    while time.perf_counter() - t_pw < a.prewarm:      # the checks above let the clocks drop again
-        lib.kh_time_infer_device(nn.handle, C.c_void_p(x.data_ptr()), B, C.c_void_p(policy.data_ptr()),
-                                 C.c_void_p(vfull.data_ptr()), 500, C.byref(ms))
-    rc = lib.kh_time_infer_device(nn.handle, C.c_void_p(x.data_ptr()), B, C.c_void_p(policy.data_ptr()),
-                                  C.c_void_p(vfull.data_ptr()), iters, C.byref(ms))
-    if rc:
-        raise RuntimeError(L.last_error())
-    flops = W.flops_per_eval(F, Cc, R) * B
-    achieved = flops / (ms.value * 1e-3) / 1e12
-    peak = PEAK_TFLOPS[a.dtype]
+    ms, _ = leg.settled_ms(a.prewarm, max(200, min(a.steps, 2000)) * (dt / a.steps))
 
     if rank == 0:
+        roof = leg.roofline(ms)
+        traffic, source = measured_traffic(F, Cc, R, B, a.dtype)
+        roof["traffic"] = traffic
+        roof["traffic_source"] = source
         out = {
-            "metric": baseline_metric(),
+            "metric": metric_label(B, F),
             "value": round(world * B * a.steps / dt, 1),
             "unit": "leaf-evals/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": round(dt / a.steps * 1e3, 5),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": a.dtype, "data": "synthetic",
-            "config": {"workload": f"{B} random boards x ({F}x8x8) planes per GPU, {R}-block x {Cc}-filter net, "
-                                   f"batched leaf evaluate() forward (BASELINE configs[1])",
+            "config": {"workload": workload_label(B, F, R, Cc),
                        "batch_per_gpu": B, "features": F, "filters": Cc, "residuals": R,
                        "parallelism": f"replicas x{world}, no data-path collective"},
-            "roofline": {"bound": "mfma", "achieved": round(achieved, 3), "peak": peak, "unit": "TFLOP/s",
-                         "frac": round(achieved / peak, 5),
-                         "traffic": measured_traffic(F, Cc, R, B, a.dtype),
-                         "kernel_ms": round(ms.value, 5),
-                         "flops_per_launch": flops},
+            "roofline": roof,
+            "distribution": {"unit": "leaf-evals/s per GPU (this rank)", "repeats": len(rates), "steps_per_repeat": per,
+                             "p10": round(pct(0.10), 1), "median": round(pct(0.50), 1), "p90": round(pct(0.90), 1)},
         }
+        if world == 1 and not a.no_variants:
+            del leg
+            torch.cuda.empty_cache()
+            out["variants"] = variant_legs(torch, lib, NN, W, L, dev_index, a.prewarm)
+            out["end_to_end"] = end_to_end_legs(NN, W, L, dev_index)
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(F, Cc, R, B)
         print(json.dumps(out), flush=True)

@@ -177,9 +177,39 @@ int  kh_encode_infer_legal(kh_engine* e, const kh_board* boards, int batch,
                            const int32_t* action_offsets, const int32_t* actions,
                            float* priors, float* value);
 
-/* Device-resident variants (pointers are HIP device pointers, `stream` is a
- * hipStream_t or NULL for the engine's own stream).  Asynchronous: no host sync,
- * no NaN check.  d_value_full is [batch][256]. */
+/* ---- submit / wait: the engine's coalescing queue (SURVEY 8b threading row) ----------------------------------
+ * The reference's callers (selfplay.cpp:196 on `inference_threads` threads, evaluate.cpp:138,147) each bring a small
+ * batch.  kh_submit_* queues one such batch and returns a ticket at once; kh_wait blocks until its results are in the
+ * caller's buffers and returns the status kh_infer / kh_encode_infer_legal would have (the NaN codes included, attributed
+ * to the submission whose rows hold the NaN).  Submissions of different callers that are queued while a launch is in
+ * flight are evaluated as ONE launch (up to 1024 positions).  All buffers — inputs too — stay the caller's and must stay
+ * valid and untouched until kh_wait returns.  At most KH_MAX_OUTSTANDING tickets per engine may be un-waited: one more
+ * kh_submit_* returns KH_ERR_INVALID (it never blocks on the caller's own outstanding work).  A submission holds at most
+ * 512 positions (kh_submit_encode_infer_legal) / 128 positions (kh_submit_infer); larger batches gain nothing from
+ * merging and take the synchronous calls.  The synchronous kh_infer / kh_encode_infer_legal use this queue themselves
+ * whenever several small calls are inside the engine at the same moment, and the private-slot path otherwise. */
+#define KH_MAX_OUTSTANDING 64
+int  kh_submit_infer(kh_engine* e, const float* input, int batch, float* policy, float* value, int64_t* ticket);
+int  kh_submit_encode_infer_legal(kh_engine* e, const kh_board* boards, int batch,
+                                  const int32_t* action_offsets, const int32_t* actions,
+                                  float* priors, float* value, int64_t* ticket);
+int  kh_wait(kh_engine* e, int64_t ticket);
+/* Launch policy of the queue.  target_batch 0 (default): whatever has accumulated goes as soon as a launch lane is
+ * free.  target_batch > 0: a batch waits until it holds that many positions, but at most max_wait_us after its first
+ * submission — for callers that know how many positions they keep in flight (the self-play pool). */
+int  kh_set_coalesce(kh_engine* e, int target_batch, int max_wait_us);
+/* launches made by the queue so far and the positions they held (mean coalesced batch = rows / launches) */
+int  kh_coalesce_stats(kh_engine* e, int64_t* launches, int64_t* rows);
+
+/* Device-resident variants (pointers are HIP device pointers).  Asynchronous: no host sync, no NaN check.
+ * d_value_full is [batch][256].
+ * `stream` is a hipStream_t; NULL means the ENGINE'S OWN non-blocking stream — not the legacy default stream
+ * (handle 0, which is what e.g. torch.cuda.current_stream() reports by default): with NULL the kernels are
+ * unordered against work the caller queued elsewhere, so the inputs must already be complete and the caller
+ * synchronises (kh_sync) before reading results.  Calls on different streams may overlap only as far as the
+ * engine's scratch allows: networks that run layer by layer (fp32, > 64 filters) keep activations in one
+ * per-engine scratch, so each call is ordered behind the previous one by an event; the whole-network kernel
+ * (bf16 / f16, <= 64 filters) has no such scratch. */
 int  kh_infer_device(kh_engine* e, const void* d_input, int batch,
                      float* d_policy, float* d_value_full, void* stream);
 int  kh_encode_device(kh_engine* e, const kh_board* d_boards, int batch,

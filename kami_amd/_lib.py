@@ -13,6 +13,7 @@ KH_OK, KH_ERR_INVALID, KH_ERR_HIP, KH_ERR_NO_WEIGHTS = 0, 1, 2, 3
 KH_ERR_NAN_POLICY, KH_ERR_NAN_VALUE, KH_ERR_NO_DEVICE = 4, 5, 6
 KH_F32, KH_BF16, KH_F16 = 0, 1, 2
 KH_VALUE_REFERENCE_FLAT, KH_VALUE_PER_SAMPLE0 = 0, 1
+KH_MAX_OUTSTANDING = 64
 DTYPES = {"f32": KH_F32, "fp32": KH_F32, "bf16": KH_BF16, "f16": KH_F16, "fp16": KH_F16}
 
 
@@ -53,6 +54,11 @@ SYMBOLS = {
     "kh_encode_infer": (C.c_int, [_P, _P, C.c_int, _P, _P]),
     "kh_infer_legal": (C.c_int, [_P, _P, C.c_int, _P, _P, _P, _P]),
     "kh_encode_infer_legal": (C.c_int, [_P, _P, C.c_int, _P, _P, _P, _P]),
+    "kh_submit_infer": (C.c_int, [_P, _P, C.c_int, _P, _P, C.POINTER(C.c_int64)]),
+    "kh_submit_encode_infer_legal": (C.c_int, [_P, _P, C.c_int, _P, _P, _P, _P, C.POINTER(C.c_int64)]),
+    "kh_wait": (C.c_int, [_P, C.c_int64]),
+    "kh_set_coalesce": (C.c_int, [_P, C.c_int, C.c_int]),
+    "kh_coalesce_stats": (C.c_int, [_P, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
     "kh_infer_device": (C.c_int, [_P, _P, C.c_int, _P, _P, _P]),
     "kh_encode_device": (C.c_int, [_P, _P, C.c_int, _P, _P]),
     "kh_encode_infer_device": (C.c_int, [_P, _P, C.c_int, _P, _P, _P]),

@@ -8,6 +8,8 @@
 #include "torch_archive.h"
 
 #include <atomic>
+#include <chrono>
+#include <thread>
 #include <cmath>
 #include <condition_variable>
 #include <cstdarg>
@@ -383,7 +385,14 @@ struct Slot {
     PinMem hin, hout;
     bool busy = false;
     bool flags_clean = false;    // device NaN flags known to be zero
+    // device-pointer API: the scratch above is shared by every caller stream, so a call on another stream
+    // than the previous one first waits for that call's last kernel (event recorded behind it)
+    hipEvent_t scratch_done = nullptr;
+    hipStream_t scratch_stream = nullptr;
+    bool scratch_pending = false;
 };
+
+struct Coalescer;       // the submit / wait queue, below
 
 }  // namespace
 
@@ -398,6 +407,10 @@ struct kh_engine {
     std::vector<std::unique_ptr<Slot>> slots;
     std::unique_ptr<Slot> devslot;           // scratch for the device-pointer API
     std::mutex dmu;
+    Coalescer* co = nullptr;          // submit / wait queue (created on first use)
+    std::mutex co_mu;
+    std::atomic<int> small_calls{ 0 };       // synchronous small-batch calls currently inside the engine
+    std::atomic<int> co_target{ 0 }, co_wait_us{ 0 };
 };
 
 namespace {
@@ -689,6 +702,275 @@ int infer_host(kh_engine* e, const float* input, const kh_board* boards, int bat
     return KH_OK;
 }
 
+
+// ------------------------------------------------------------------------------- coalescing queue
+// SURVEY §8(b), threading row: "per-thread stream + staging slot, OR internal queue that coalesces callers into
+// bigger batches".  The slots above are the first; this is the second.  Callers hand over small batches
+// (kh_submit_* returns a ticket at once, kh_wait blocks for it; the synchronous entry points use the same queue when
+// other small calls are in flight), each caller copies its own rows into the open batch's merge buffers, and two lane
+// threads turn whatever has accumulated into ONE launch each (one pinned block each way, infer_host's packed path),
+// then scatter priors / policy rows / values straight into the callers' buffers.  While a launch is in flight the
+// next batch fills up, so the batch size adapts to the load; kh_set_coalesce adds a target size and a bounded wait
+// for callers that know how much will be in flight (the self-play pool).
+//
+// Never blocks a submitter on its own outstanding work: tickets are a fixed pool (exhaustion -> KH_ERR_INVALID),
+// merge buffers are handed back as soon as their launch has completed (results are already in the callers'
+// buffers), so the only wait inside kh_submit_* is for a launch that is already on the device.
+constexpr int CO_ROWS = 1024;                   // boards per coalesced launch (merge buffer capacity)
+constexpr int CO_ACTS = CO_ROWS * 48;           // legal actions per coalesced launch
+constexpr int CO_SMALL_LEGAL = 512;             // a submission larger than this takes the direct path
+constexpr int CO_SMALL_PLANES = 128;
+constexpr int CO_BUFFERS = 4;
+constexpr int CO_LANES = 2;
+
+struct CoTicket {
+    uint32_t serial = 0;
+    int state = 0;                              // 0 free, 1 queued, 2 done
+    int status = KH_OK;
+    std::string err;
+    int kind = 0, row0 = 0, rows = 0, act0 = 0, nact = 0;
+    // the caller's buffers (valid until kh_wait returns): inputs for the rare per-ticket re-run, outputs for the scatter
+    const kh_board* boards = nullptr; const float* planes = nullptr;
+    const int32_t *offsets = nullptr, *actions = nullptr;
+    float *priors = nullptr, *value = nullptr, *policy = nullptr;
+};
+
+struct CoBatch {
+    int state = 0;                              // 0 free, 1 open, 2 sealed (a lane owns it)
+    int kind = 0;                               // 0: records + legal actions -> priors; 1: planes -> full policy rows
+    int rows = 0, nact = 0, copying = 0;
+    bool full = false;
+    std::chrono::steady_clock::time_point first;
+    std::vector<CoTicket*> tickets;
+    std::vector<kh_board> boards;
+    std::vector<int32_t> offsets, actions;
+    std::vector<float> planes, priors, values, vfull, policy;
+};
+
+struct Coalescer {
+    kh_engine* e;
+    std::mutex mu;
+    std::condition_variable cv_lane, cv_done, cv_space;
+    CoTicket tickets[KH_MAX_OUTSTANDING];
+    CoBatch batches[CO_BUFFERS];
+    std::thread lanes[CO_LANES];
+    int lanes_busy = 0;
+    bool stop = false;
+    int64_t launches = 0, rows_launched = 0;
+};
+
+void co_run_batch(kh_engine* e, CoBatch& b)
+{
+    const int B = b.rows;
+    int rc;
+    const bool flat = e->cfg.value_mode == KH_VALUE_REFERENCE_FLAT;
+    if (b.kind == 0) {
+        b.priors.resize((size_t)std::max(b.nact, 1));
+        b.values.resize((size_t)B);
+        LegalIO l{ b.offsets.data(), b.actions.data(), b.priors.data() };
+        if (flat) {
+            // nn.cpp:186 hands back the first `batch` floats of the caller's OWN flattened [batch,256] tensor: take the
+            // whole tensor and cut each caller's slice out of it below
+            b.vfull.resize((size_t)B * KH_VALUE_WIDTH);
+            rc = infer_host(e, nullptr, b.boards.data(), B, nullptr, nullptr, b.vfull.data(), nullptr, &l);
+        } else {
+            rc = infer_host(e, nullptr, b.boards.data(), B, nullptr, b.values.data(), nullptr, nullptr, &l);
+        }
+    } else {
+        b.policy.resize((size_t)B * KH_PSIZE);
+        b.vfull.resize((size_t)B * KH_VALUE_WIDTH);
+        rc = infer_host(e, b.planes.data(), nullptr, B, b.policy.data(), nullptr, b.vfull.data(), nullptr);
+    }
+    const std::string err = rc ? g_err : std::string();
+    for (CoTicket* t : b.tickets) {
+        if (rc == KH_ERR_NAN_POLICY || rc == KH_ERR_NAN_VALUE) {
+            // a NaN somewhere in the merged batch: the reference's exception belongs to the caller whose rows hold it.
+            // Rare: run every ticket of this batch on its own (its inputs are still the caller's to keep until kh_wait).
+            if (t->kind == 0) {
+                LegalIO l{ t->offsets, t->actions, t->priors };
+                t->status = infer_host(e, nullptr, t->boards, t->rows, nullptr, t->value, nullptr, nullptr, &l);
+            } else {
+                t->status = infer_host(e, t->planes, nullptr, t->rows, t->policy, t->value, nullptr, nullptr);
+            }
+            t->err = t->status ? g_err : std::string();
+            continue;
+        }
+        t->status = rc; t->err = err;
+        if (rc) continue;
+        if (t->kind == 0) {
+            if (t->nact) memcpy(t->priors, b.priors.data() + t->act0, (size_t)t->nact * 4);
+        } else {
+            memcpy(t->policy, b.policy.data() + (size_t)t->row0 * KH_PSIZE, (size_t)t->rows * KH_PSIZE * 4);
+        }
+        if (b.kind == 0 && !flat) memcpy(t->value, b.values.data() + t->row0, (size_t)t->rows * 4);
+        else if (flat) memcpy(t->value, b.vfull.data() + (size_t)t->row0 * KH_VALUE_WIDTH, (size_t)t->rows * 4);    // rows <= 256 here
+        else for (int i = 0; i < t->rows; ++i) t->value[i] = b.vfull[(size_t)(t->row0 + i) * KH_VALUE_WIDTH];
+    }
+}
+
+void co_lane(Coalescer* c)
+{
+    kh_engine* e = c->e;
+    std::unique_lock<std::mutex> lk(c->mu);
+    for (;;) {
+        CoBatch* take = nullptr;
+        auto deadline = std::chrono::steady_clock::time_point::max();
+        const int target = e->co_target.load(), wait_us = e->co_wait_us.load();
+        for (auto& b : c->batches) {
+            if (b.state != 1 || b.rows == 0) continue;
+            // immediate mode (no target): whatever has accumulated goes as soon as a lane is free;
+            // target mode: wait for `target` rows, at most wait_us after the batch's first submission
+            bool ready = b.full || target <= 0 || b.rows >= target;
+            if (!ready) {
+                const auto due = b.first + std::chrono::microseconds(wait_us);
+                if (std::chrono::steady_clock::now() >= due) ready = true;
+                else deadline = std::min(deadline, due);
+            }
+            if (ready) { take = &b; break; }
+        }
+        if (!take) {
+            if (c->stop) return;
+            if (deadline == std::chrono::steady_clock::time_point::max()) c->cv_lane.wait(lk);
+            else c->cv_lane.wait_until(lk, deadline);
+            continue;
+        }
+        take->state = 2;
+        ++c->lanes_busy;
+        while (take->copying > 0) c->cv_lane.wait(lk);          // submitters still copying their rows in
+        lk.unlock();
+        co_run_batch(e, *take);
+        lk.lock();
+        --c->lanes_busy;
+        c->launches += 1; c->rows_launched += take->rows;
+        for (CoTicket* t : take->tickets) t->state = 2;
+        take->tickets.clear();
+        take->rows = take->nact = 0; take->full = false; take->state = 0;
+        c->cv_done.notify_all();
+        c->cv_space.notify_all();
+    }
+}
+
+Coalescer* co_get(kh_engine* e)
+{
+    std::lock_guard<std::mutex> lk(e->co_mu);
+    if (!e->co) {
+        Coalescer* c = new Coalescer();
+        c->e = e;
+        for (auto& l : c->lanes) l = std::thread(co_lane, c);
+        e->co = c;
+    }
+    return e->co;
+}
+
+void co_destroy(kh_engine* e)
+{
+    Coalescer* c = e->co;
+    if (!c) return;
+    { std::lock_guard<std::mutex> lk(c->mu); c->stop = true; }
+    c->cv_lane.notify_all();
+    for (auto& l : c->lanes) if (l.joinable()) l.join();
+    delete c;
+    e->co = nullptr;
+}
+
+int co_submit(kh_engine* e, int kind, const kh_board* boards, const float* planes, int batch, const int32_t* offsets,
+              const int32_t* actions, float* priors, float* value, float* policy, int64_t* ticket)
+{
+    if (!e || !ticket || !value || batch < 1) return fail(KH_ERR_INVALID, "bad submit arguments");
+    int nact = 0;
+    if (kind == 0) {
+        if (!boards || !offsets || !actions || !priors) return fail(KH_ERR_INVALID, "null buffer");
+        if (e->cfg.features != KH_NFEATURES) return fail(KH_ERR_INVALID, "compact records need features == %d", KH_NFEATURES);
+        if (offsets[0] != 0) return fail(KH_ERR_INVALID, "action_offsets[0] must be 0");
+        for (int i = 0; i < batch; ++i)
+            if (offsets[i + 1] < offsets[i]) return fail(KH_ERR_INVALID, "action_offsets must be non-decreasing");
+        nact = offsets[batch];
+        if (batch > CO_SMALL_LEGAL || nact > CO_ACTS) return fail(KH_ERR_INVALID, "submissions hold at most %d positions / %d actions (use the synchronous call for more)", CO_SMALL_LEGAL, CO_ACTS);
+    } else {
+        if (!planes || !policy) return fail(KH_ERR_INVALID, "null buffer");
+        if (batch > CO_SMALL_PLANES) return fail(KH_ERR_INVALID, "plane submissions hold at most %d positions (use kh_infer for more)", CO_SMALL_PLANES);
+    }
+    if (!current_weights(e)) return fail(KH_ERR_NO_WEIGHTS, "submit before kh_load_weights");
+    Coalescer* c = co_get(e);
+    const size_t F = e->cfg.features;
+    const int cap_rows = kind == 0 ? CO_ROWS : 2 * CO_SMALL_PLANES;
+    std::unique_lock<std::mutex> lk(c->mu);
+    CoTicket* t = nullptr;
+    int tid = 0;
+    for (; tid < KH_MAX_OUTSTANDING; ++tid)
+        if (c->tickets[tid].state == 0) { t = &c->tickets[tid]; break; }
+    if (!t) return fail(KH_ERR_INVALID, "%d submissions are outstanding on this engine: kh_wait for some before submitting more", KH_MAX_OUTSTANDING);
+    CoBatch* b = nullptr;
+    for (;;) {
+        for (auto& x : c->batches)
+            if (x.state == 1 && x.kind == kind && !x.full) {
+                if (x.rows + batch <= cap_rows && x.nact + nact <= CO_ACTS) { b = &x; break; }
+                x.full = true;                                   // does not fit: it goes as it is
+                c->cv_lane.notify_all();
+            }
+        if (b) break;
+        for (auto& x : c->batches)
+            if (x.state == 0) { b = &x; break; }
+        if (b) {
+            b->state = 1; b->kind = kind; b->rows = 0; b->nact = 0; b->full = false;
+            b->first = std::chrono::steady_clock::now();
+            if (kind == 0) {
+                if (b->boards.empty()) { b->boards.resize(CO_ROWS); b->offsets.resize(CO_ROWS + 1); b->actions.resize(CO_ACTS); }
+                b->offsets[0] = 0;
+            } else if (b->planes.size() < (size_t)cap_rows * 64 * F) b->planes.resize((size_t)cap_rows * 64 * F);
+            break;
+        }
+        c->cv_space.wait(lk);                                    // every buffer is on the device: one of them comes back
+    }
+    t->state = 1; t->status = KH_OK; t->err.clear(); ++t->serial;
+    t->kind = kind; t->row0 = b->rows; t->rows = batch; t->act0 = b->nact; t->nact = nact;
+    t->boards = boards; t->planes = planes; t->offsets = offsets; t->actions = actions;
+    t->priors = priors; t->value = value; t->policy = policy;
+    b->rows += batch; b->nact += nact;
+    b->tickets.push_back(t);
+    ++b->copying;
+    lk.unlock();
+    // this caller's rows into the merge buffers (every caller copies its own, in parallel)
+    if (kind == 0) {
+        memcpy(b->boards.data() + t->row0, boards, (size_t)batch * sizeof(kh_board));
+        if (nact) memcpy(b->actions.data() + t->act0, actions, (size_t)nact * 4);
+        for (int i = 1; i <= batch; ++i) b->offsets[t->row0 + i] = t->act0 + offsets[i];
+    } else {
+        memcpy(b->planes.data() + (size_t)t->row0 * 64 * F, planes, (size_t)batch * 64 * F * 4);
+    }
+    lk.lock();
+    --b->copying;
+    lk.unlock();
+    c->cv_lane.notify_all();
+    *ticket = (int64_t)tid | ((int64_t)t->serial << 32);
+    return KH_OK;
+}
+
+int co_wait(kh_engine* e, int64_t ticket)
+{
+    if (!e || !e->co) return fail(KH_ERR_INVALID, "no such ticket");
+    Coalescer* c = e->co;
+    const int tid = (int)(ticket & 0xffffffff);
+    const uint32_t serial = (uint32_t)(ticket >> 32);
+    if (tid < 0 || tid >= KH_MAX_OUTSTANDING) return fail(KH_ERR_INVALID, "no such ticket");
+    std::unique_lock<std::mutex> lk(c->mu);
+    CoTicket& t = c->tickets[tid];
+    if (t.state == 0 || t.serial != serial) return fail(KH_ERR_INVALID, "ticket already waited for (or never issued)");
+    while (t.state != 2) c->cv_done.wait(lk);
+    const int rc = t.status;
+    if (rc) g_err = t.err;
+    t.state = 0;
+    return rc;
+}
+
+// a synchronous small call goes through the queue when other small calls are inside the engine right now
+struct SmallCall {
+    kh_engine* e;
+    bool others;
+    explicit SmallCall(kh_engine* e_) : e(e_) { others = e->small_calls.fetch_add(1) > 0; }
+    ~SmallCall() { e->small_calls.fetch_sub(1); }
+};
+
 }  // namespace
 
 // =============================================================================== C ABI
@@ -743,8 +1025,12 @@ int kh_create(const kh_config* cfg, kh_engine** out)
 void kh_destroy(kh_engine* e)
 {
     if (!e) return;
+    co_destroy(e);
     (void)hipSetDevice(e->cfg.device);
-    auto kill = [](Slot* s) { if (s && s->stream) { (void)hipStreamSynchronize(s->stream); (void)hipStreamDestroy(s->stream); } };
+    auto kill = [](Slot* s) {
+        if (s && s->stream) { (void)hipStreamSynchronize(s->stream); (void)hipStreamDestroy(s->stream); }
+        if (s && s->scratch_done) (void)hipEventDestroy(s->scratch_done);
+    };
     for (auto& s : e->slots) kill(s.get());
     kill(e->devslot.get());
     delete e;
@@ -989,7 +1275,49 @@ int kh_clone(kh_engine* src, kh_engine** out)
 int kh_infer(kh_engine* e, const float* input, int batch, float* policy, float* value)
 {
     if (!value) return fail(KH_ERR_INVALID, "null value buffer");
+    if (e && input && policy && batch >= 1 && batch <= CO_SMALL_PLANES) {
+        SmallCall sc(e);
+        if (sc.others) {                 // concurrent small callers (selfplay.cpp's inference threads): one launch for all
+            int64_t t;
+            const int rc = co_submit(e, 1, nullptr, input, batch, nullptr, nullptr, nullptr, value, policy, &t);
+            return rc ? rc : co_wait(e, t);
+        }
+        return infer_host(e, input, nullptr, batch, policy, value, nullptr, nullptr);
+    }
     return infer_host(e, input, nullptr, batch, policy, value, nullptr, nullptr);
+}
+
+int kh_submit_infer(kh_engine* e, const float* input, int batch, float* policy, float* value, int64_t* ticket)
+{
+    return co_submit(e, 1, nullptr, input, batch, nullptr, nullptr, nullptr, value, policy, ticket);
+}
+
+int kh_submit_encode_infer_legal(kh_engine* e, const kh_board* boards, int batch, const int32_t* action_offsets,
+                                 const int32_t* actions, float* priors, float* value, int64_t* ticket)
+{
+    return co_submit(e, 0, boards, nullptr, batch, action_offsets, actions, priors, value, nullptr, ticket);
+}
+
+int kh_wait(kh_engine* e, int64_t ticket) { return co_wait(e, ticket); }
+
+int kh_set_coalesce(kh_engine* e, int target_batch, int max_wait_us)
+{
+    if (!e || target_batch < 0 || target_batch > CO_ROWS || max_wait_us < 0 || max_wait_us > 1000000)
+        return fail(KH_ERR_INVALID, "target_batch in [0, %d], max_wait_us in [0, 1000000]", CO_ROWS);
+    e->co_target = target_batch;
+    e->co_wait_us = max_wait_us;
+    if (e->co) e->co->cv_lane.notify_all();
+    return KH_OK;
+}
+
+int kh_coalesce_stats(kh_engine* e, int64_t* launches, int64_t* rows)
+{
+    if (!e) return fail(KH_ERR_INVALID, "null engine");
+    int64_t l = 0, r = 0;
+    if (e->co) { std::lock_guard<std::mutex> lk(e->co->mu); l = e->co->launches; r = e->co->rows_launched; }
+    if (launches) *launches = l;
+    if (rows) *rows = r;
+    return KH_OK;
 }
 
 int kh_infer_full(kh_engine* e, const float* input, int batch, float* policy, float* value_full,
@@ -1022,6 +1350,14 @@ int kh_encode_infer_legal(kh_engine* e, const kh_board* boards, int batch, const
     if (e->cfg.features != KH_NFEATURES)
         return fail(KH_ERR_INVALID, "kh_encode_infer_legal needs features == %d (Env::observe planes)", KH_NFEATURES);
     if (!value || !boards) return fail(KH_ERR_INVALID, "null buffer");
+    if (batch >= 1 && batch <= CO_SMALL_LEGAL / 4 && action_offsets && actions && priors) {
+        SmallCall sc(e);
+        if (sc.others) {
+            int64_t t;
+            const int rc = co_submit(e, 0, boards, nullptr, batch, action_offsets, actions, priors, value, nullptr, &t);
+            return rc ? rc : co_wait(e, t);
+        }
+    }
     LegalIO l{ action_offsets, actions, priors };
     return infer_host(e, nullptr, boards, batch, nullptr, value, nullptr, nullptr, &l);
 }
@@ -1053,7 +1389,23 @@ static int dev_slot(kh_engine* e, int batch, void* stream, Slot** out)
     int rc = slot_ensure(e, s, batch, false);
     if (rc) return rc;
     *out = &s;
-    (void)stream;
+    // per-layer paths keep activations in the slot's scratch: order this call behind the previous one when it
+    // runs on a different stream (same stream: stream order already does it)
+    hipStream_t st = stream ? static_cast<hipStream_t>(stream) : s.stream;
+    if (s.scratch_pending && s.scratch_stream != st) HIPCHK(hipStreamWaitEvent(st, s.scratch_done, 0));
+    return KH_OK;
+}
+
+// after a device-API forward: remember where the scratch was last used (only the per-layer paths use it; the
+// whole-network kernel keeps its activations in LDS)
+static int dev_slot_done(kh_engine* e, const Weights& W, Slot& s, hipStream_t st)
+{
+    const bool uses_scratch = e->cfg.dtype == KH_F32 || !W.tw_ok;
+    if (!uses_scratch) return KH_OK;
+    if (!s.scratch_done) HIPCHK(hipEventCreateWithFlags(&s.scratch_done, hipEventDisableTiming));
+    HIPCHK(hipEventRecord(s.scratch_done, st));
+    s.scratch_stream = st;
+    s.scratch_pending = true;
     return KH_OK;
 }
 
@@ -1073,6 +1425,7 @@ int kh_infer_device(kh_engine* e, const void* d_input, int batch, float* d_polic
     hipStream_t own = s->stream;
     if (stream) s->stream = static_cast<hipStream_t>(stream);
     rc = forward_dispatch(e, *W, *s, static_cast<const float*>(d_input), batch, d_policy, d_value_full, nullptr);
+    if (!rc) rc = dev_slot_done(e, *W, *s, s->stream);
     s->stream = own;
     return rc;
 }
@@ -1114,6 +1467,7 @@ int kh_encode_infer_device(kh_engine* e, const kh_board* d_boards, int batch, fl
         if (s->planes.ensure((size_t)batch * 64 * KH_NFEATURES * 4)) { s->stream = own; return KH_ERR_HIP; }
         kh::launch_encode_f32(d_boards, batch, s->planes.as<float>(), s->stream);
         rc = forward_dispatch(e, *W, *s, s->planes.as<float>(), batch, d_policy, d_value_full, nullptr);
+        if (!rc) rc = dev_slot_done(e, *W, *s, s->stream);
     }
     s->stream = own;
     return rc;

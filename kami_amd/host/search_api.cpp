@@ -236,61 +236,124 @@ void advance_game(ks_pool* p, ks_pool::Game& g)
     if (env.terminal(&value)) finish_game(p, g, value);
 }
 
-void worker(ks_pool* p, int g0, int g1, int64_t target_evals, double deadline_s, std::chrono::steady_clock::time_point t0)
-{
-    const int L = p->cfg.leaves_per_tree > 0 ? p->cfg.leaves_per_tree : 1;
+// One batch of a worker: the leaves of a contiguous range of its trees (up to L per tree), as the engine wants them.
+struct LeafSet {
+    int g0 = 0, g1 = 0;
     std::vector<kh_board> boards;
     std::vector<int32_t> offsets, actions;
     std::vector<float> priors, values;
     std::vector<std::pair<int, int>> owner;         // (game, leaf slot) of each batch row
-    try {
-        for (;;) {
-            if (p->evals.load() >= target_evals) break;
-            if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > deadline_s) break;
-            boards.clear(); offsets.assign(1, 0); actions.clear(); owner.clear();
-            for (int gi = g0; gi < g1; ++gi) {
-                ks_pool::Game& g = p->games[gi];
-                MCTS& tree = *g.tree;
-                if (gi + 2 < g1) p->games[gi + 2].tree->prefetch();     // a worker's trees do not fit its caches
-                if ((int)g.leaves.size() < L) g.leaves.resize((size_t)L);
-                g.nleaves = 0;
-                for (;;) {
-                    if (g.nleaves == 0 && tree.n() >= p->cfg.nodes) { advance_game(p, g); continue; }
-                    if (g.nleaves >= L || tree.n() + g.nleaves >= p->cfg.nodes) break;
-                    bool blocked = false;
-                    if (tree.select_leaf(&g.leaves[g.nleaves], &blocked)) { ++g.nleaves; continue; }
-                    if (blocked) break;
-                }
-                for (int j = 0; j < g.nleaves; ++j) {
-                    boards.push_back(g.leaves[j].record);
-                    actions.insert(actions.end(), g.leaves[j].actions.begin(), g.leaves[j].actions.end());
-                    offsets.push_back((int32_t)actions.size());
-                    owner.emplace_back(gi, j);
-                }
+    int64_t ticket = 0;
+    bool in_flight = false;
+    std::chrono::steady_clock::time_point t_submit;
+
+    // select -> records + legal actions (selfplay.cpp:113-193); trees that reached their visit budget play a move first
+    int build(ks_pool* p, int L)
+    {
+        boards.clear(); offsets.assign(1, 0); actions.clear(); owner.clear();
+        for (int gi = g0; gi < g1; ++gi) {
+            ks_pool::Game& g = p->games[gi];
+            MCTS& tree = *g.tree;
+            if (gi + 2 < g1) p->games[gi + 2].tree->prefetch();     // a worker's trees do not fit its caches
+            if ((int)g.leaves.size() < L) g.leaves.resize((size_t)L);
+            g.nleaves = 0;
+            for (;;) {
+                if (g.nleaves == 0 && tree.n() >= p->cfg.nodes) { advance_game(p, g); continue; }
+                if (g.nleaves >= L || tree.n() + g.nleaves >= p->cfg.nodes) break;
+                bool blocked = false;
+                if (tree.select_leaf(&g.leaves[g.nleaves], &blocked)) { ++g.nleaves; continue; }
+                if (blocked) break;
             }
-            const int nb = (int)boards.size();
-            if (nb == 0) continue;
-            priors.resize(actions.size());
-            values.resize((size_t)nb);
-            const auto e0 = std::chrono::steady_clock::now();
-            const int rc = kh_encode_infer_legal(p->engine, boards.data(), nb, offsets.data(), actions.data(), priors.data(), values.data());
-            p->engine_ns += std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - e0).count();
-            if (rc != KH_OK) throw std::runtime_error(std::string("kh_encode_infer_legal: ") + kh_last_error());
-            for (int j = 0; j < nb; ++j) {
-                if (j + 2 < nb) { ks_pool::Game& a = p->games[owner[j + 2].first]; a.tree->prefetch_expand(a.leaves[owner[j + 2].second]); }
-                ks_pool::Game& g = p->games[owner[j].first];
-                g.tree->expand_leaf(g.leaves[owner[j].second], priors.data() + offsets[j], values[j]);
-                if (owner[j].second + 1 == g.nleaves) g.nleaves = 0;       // nleaves > 0 <=> leaves marked in the tree
+            for (int j = 0; j < g.nleaves; ++j) {
+                boards.push_back(g.leaves[j].record);
+                actions.insert(actions.end(), g.leaves[j].actions.begin(), g.leaves[j].actions.end());
+                offsets.push_back((int32_t)actions.size());
+                owner.emplace_back(gi, j);
             }
-            p->evals += nb;
-            p->batches += 1;
         }
-    } catch (std::exception& e) {
-        // a failed engine call must not leave virtual visits behind: the pool can be run again
+        priors.resize(actions.size() + 1);
+        values.resize(boards.size() + 1);
+        return (int)boards.size();
+    }
+
+    // expand with the evaluator's answer (selfplay.cpp:199-200)
+    void expand(ks_pool* p)
+    {
+        const int nb = (int)boards.size();
+        for (int j = 0; j < nb; ++j) {
+            if (j + 2 < nb) { ks_pool::Game& a = p->games[owner[j + 2].first]; a.tree->prefetch_expand(a.leaves[owner[j + 2].second]); }
+            ks_pool::Game& g = p->games[owner[j].first];
+            g.tree->expand_leaf(g.leaves[owner[j].second], priors.data() + offsets[j], values[j]);
+            if (owner[j].second + 1 == g.nleaves) g.nleaves = 0;       // nleaves > 0 <=> leaves marked in the tree
+        }
+        p->evals += nb;
+        p->batches += 1;
+    }
+
+    void release(ks_pool* p)
+    {
         for (int gi = g0; gi < g1; ++gi) {
             ks_pool::Game& g = p->games[gi];
             for (int j = 0; j < g.nleaves; ++j) g.tree->release_leaf(g.leaves[j]);
             g.nleaves = 0;
+        }
+    }
+};
+
+void worker(ks_pool* p, int g0, int g1, int64_t target_evals, double deadline_s, std::chrono::steady_clock::time_point t0)
+{
+    const int L = p->cfg.leaves_per_tree > 0 ? p->cfg.leaves_per_tree : 1;
+    // pipeline: the worker's trees in two halves, each half one submission to the engine's queue — while one half is
+    // on the device the other is expanded and selected (kh_submit_encode_infer_legal / kh_wait); otherwise one blocking
+    // call per round over all of its trees (the reference's schedule, selfplay.cpp:196)
+    const bool pipeline = p->cfg.pipeline != 0 && g1 - g0 >= 2;
+    LeafSet sets[2];
+    sets[0].g0 = g0; sets[0].g1 = pipeline ? g0 + (g1 - g0) / 2 : g1;
+    sets[1].g0 = sets[0].g1; sets[1].g1 = g1;
+    auto now = [] { return std::chrono::steady_clock::now(); };
+    auto stop = [&] {
+        return p->evals.load() >= target_evals || std::chrono::duration<double>(now() - t0).count() > deadline_s;
+    };
+    auto finish = [&](LeafSet& s) {                      // wait for a submitted set and expand it
+        const int rc = kh_wait(p->engine, s.ticket);
+        s.in_flight = false;
+        p->engine_ns += std::chrono::duration_cast<std::chrono::nanoseconds>(now() - s.t_submit).count();
+        if (rc != KH_OK) throw std::runtime_error(std::string("kh_encode_infer_legal: ") + kh_last_error());
+        s.expand(p);
+    };
+    try {
+        if (!pipeline) {
+            LeafSet& s = sets[0];
+            while (!stop()) {
+                const int nb = s.build(p, L);
+                if (nb == 0) continue;
+                const auto e0 = now();
+                const int rc = kh_encode_infer_legal(p->engine, s.boards.data(), nb, s.offsets.data(), s.actions.data(), s.priors.data(), s.values.data());
+                p->engine_ns += std::chrono::duration_cast<std::chrono::nanoseconds>(now() - e0).count();
+                if (rc != KH_OK) throw std::runtime_error(std::string("kh_encode_infer_legal: ") + kh_last_error());
+                s.expand(p);
+            }
+        } else {
+            for (int k = 0;; k ^= 1) {
+                LeafSet& s = sets[k];
+                if (s.in_flight) finish(s);
+                if (stop()) break;
+                const int nb = s.build(p, L);
+                if (nb == 0) continue;
+                s.t_submit = now();
+                const int rc = kh_submit_encode_infer_legal(p->engine, s.boards.data(), nb, s.offsets.data(), s.actions.data(), s.priors.data(),
+                                                            s.values.data(), &s.ticket);
+                if (rc != KH_OK) throw std::runtime_error(std::string("kh_encode_infer_legal: ") + kh_last_error());
+                s.in_flight = true;
+            }
+            for (auto& s : sets)
+                if (s.in_flight) finish(s);
+        }
+    } catch (std::exception& e) {
+        // a failed engine call must not leave virtual visits or tickets behind: the pool can be run again
+        for (auto& s : sets) {
+            if (s.in_flight) { (void)kh_wait(p->engine, s.ticket); s.in_flight = false; }
+            s.release(p);
         }
         std::lock_guard<std::mutex> lk(p->err_mutex);
         p->error = e.what();
@@ -306,6 +369,10 @@ int ks_pool_create(kh_engine* engine, const ks_pool_config* cfg, ks_pool** out)
     ks_pool* p = new ks_pool();
     p->engine = engine;
     p->cfg = *cfg;
+    if (cfg->pipeline && kh_set_coalesce(engine, cfg->coalesce_target, cfg->coalesce_wait_us) != KH_OK) {
+        delete p;
+        return fail("%s", kh_last_error());
+    }
     p->games.resize((size_t)cfg->games);
     for (int i = 0; i < cfg->games; ++i) {
         MCTSConfig mc;

@@ -50,6 +50,17 @@ def read_checkpoint(path: str):
     return blob, F.value, Cc.value, R.value, gen.value
 
 
+class Ticket:
+    """An outstanding kh_submit_*: keeps the caller-side buffers alive until wait() (the engine reads and writes them)."""
+
+    def __init__(self, nn, ticket, outputs, keep):
+        self._nn, self._t, self._out, self._keep = nn, ticket, outputs, keep
+
+    def wait(self):
+        _chk(self._nn._lib.kh_wait(self._nn._h, self._t))
+        return self._out
+
+
 class NN:
     def __init__(self, width: int = 8, height: int = 8, features: int = NFEATURES,
                  psize: int = PSIZE, *, filters: int = 256, residuals: int = 2,
@@ -183,6 +194,39 @@ class NN:
             x = np.ascontiguousarray(input_or_boards, dtype=np.float32)
             _chk(self._lib.kh_infer_legal(self._h, _ptr(x), n, _ptr(offs), _ptr(acts), _ptr(priors), _ptr(value)))
         return priors, value
+
+    # -- submit / wait (the engine's coalescing queue) -------------------------------------
+    def submit_infer(self, input: np.ndarray) -> "Ticket":
+        """kh_submit_infer: queue a small batch of planes; Ticket.wait() -> (policy, value).  Submissions queued while a
+        launch is in flight are evaluated as one launch."""
+        x = np.ascontiguousarray(input, dtype=np.float32)
+        batch = x.size // self.obsize()
+        policy = np.empty((batch, PSIZE), np.float32)
+        value = np.empty((batch,), np.float32)
+        t = C.c_int64()
+        _chk(self._lib.kh_submit_infer(self._h, _ptr(x), batch, _ptr(policy), _ptr(value), C.byref(t)))
+        return Ticket(self, t.value, (policy, value), (x,))
+
+    def submit_infer_legal(self, boards: np.ndarray, action_offsets: np.ndarray, actions: np.ndarray) -> "Ticket":
+        """kh_submit_encode_infer_legal; Ticket.wait() -> (priors, value)."""
+        b = np.ascontiguousarray(boards, dtype=L.BOARD_DTYPE)
+        offs = np.ascontiguousarray(action_offsets, dtype=np.int32)
+        acts = np.ascontiguousarray(actions, dtype=np.int32)
+        n = offs.size - 1
+        priors = np.empty((max(1, int(offs[-1])),), np.float32)
+        value = np.empty((n,), np.float32)
+        t = C.c_int64()
+        _chk(self._lib.kh_submit_encode_infer_legal(self._h, _ptr(b), n, _ptr(offs), _ptr(acts), _ptr(priors), _ptr(value), C.byref(t)))
+        return Ticket(self, t.value, (priors[:int(offs[-1])], value), (b, offs, acts, priors))
+
+    def set_coalesce(self, target_batch: int = 0, max_wait_us: int = 0) -> None:
+        _chk(self._lib.kh_set_coalesce(self._h, target_batch, max_wait_us))
+
+    def coalesce_stats(self):
+        """(launches made by the queue, positions they held)"""
+        a, b = C.c_int64(), C.c_int64()
+        _chk(self._lib.kh_coalesce_stats(self._h, C.byref(a), C.byref(b)))
+        return a.value, b.value
 
     @property
     def handle(self):

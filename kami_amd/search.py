@@ -24,7 +24,8 @@ class PoolConfig(C.Structure):
     _fields_ = [("games", C.c_int32), ("threads", C.c_int32), ("nodes", C.c_int32), ("leaves_per_tree", C.c_int32),
                 ("cpuct", C.c_float), ("noise_weight", C.c_float),
                 ("alpha_initial", C.c_float), ("alpha_decay", C.c_float), ("alpha_final", C.c_float),
-                ("alpha_cutoff", C.c_int32), ("draw_value_pct", C.c_int32), ("seed", C.c_uint32), ("reserved", C.c_int32 * 4)]
+                ("alpha_cutoff", C.c_int32), ("draw_value_pct", C.c_int32), ("seed", C.c_uint32),
+                ("pipeline", C.c_int32), ("coalesce_target", C.c_int32), ("coalesce_wait_us", C.c_int32), ("reserved", C.c_int32 * 1)]
 
 
 class PoolStats(C.Structure):
@@ -156,11 +157,12 @@ class Pool:
     """Self-play pool (kami/selfplay.cpp:58-213) feeding an engine (kami_amd.NN) with compact records."""
 
     def __init__(self, nn, games=512, threads=4, nodes=64, leaves_per_tree=1, cpuct=1.0, noise_weight=0.05,
-                 alpha=(1.0, 1.0, 1.0), alpha_cutoff=1, draw_value_pct=50, seed=1):
+                 alpha=(1.0, 1.0, 1.0), alpha_cutoff=1, draw_value_pct=50, seed=1, pipeline=False, coalesce_target=0,
+                 coalesce_wait_us=0):
         self.lib = load()
         self.nn = nn                      # keep the engine alive
         cfg = PoolConfig(games, threads, nodes, leaves_per_tree, cpuct, noise_weight, alpha[0], alpha[1], alpha[2],
-                         alpha_cutoff, draw_value_pct, seed)
+                         alpha_cutoff, draw_value_pct, seed, int(pipeline), coalesce_target, coalesce_wait_us)
         self.h = C.c_void_p()
         if self.lib.ks_pool_create(nn.handle, C.byref(cfg), C.byref(self.h)):
             raise RuntimeError(self.lib.ks_last_error().decode())

@@ -9,13 +9,27 @@ from conftest import record_maxima
 
 pytestmark = pytest.mark.gpu
 
-# Tolerances per arithmetic type, vs the fp32 reference (SURVEY §8c tolerance anchors).
-# logp = log-probabilities (differences of pre-softmax logits), value = tanh output.
-TOL = {
-    "f32": dict(logp=3e-4, prob_rtol=3e-4, value=3e-5),
-    "f16": dict(logp=3e-2, prob_rtol=3e-2, value=2e-3),
-    "bf16": dict(logp=2e-1, prob_rtol=2e-1, value=1.5e-2),
+# Tolerances per arithmetic type and depth class, vs the fp32 reference / oracle: each entry is <= 2x the maximum
+# this suite OBSERVED on the MI355X (profiles/r02_parity_maxima.json, written by conftest.record_maxima; per test
+# key there).  logp = log-probabilities and pre-softmax logits, prob_rtol = relative error of probabilities
+# > 1e-6, value = the tanh output.  Low-precision error grows with the number of blocks, so the deep BASELINE
+# configurations (10 and 20 blocks) carry their own, measured at full depth.
+TOL_BY_DEPTH = {
+    6: {"f32": dict(logp=1.6e-5, prob_rtol=1.6e-5, value=7.5e-7),      # observed 7.6e-6 / 7.9e-6 / 3.6e-7
+        "f16": dict(logp=1.3e-2, prob_rtol=1.3e-2, value=2.2e-4),      # observed 6.5e-3 / 6.5e-3 / 1.1e-4
+        "bf16": dict(logp=1.3e-1, prob_rtol=1.2e-1, value=2.0e-3)},    # observed 6.6e-2 / 6.1e-2 / 9.9e-4
+    10: {"f32": dict(logp=1.8e-5, prob_rtol=1.7e-5, value=9e-7),       # observed 8.6e-6 / 8.3e-6 / 4.5e-7
+         "f16": dict(logp=1.7e-2, prob_rtol=1.6e-2, value=7e-4),       # observed 8.4e-3 / 7.8e-3 / 3.5e-4
+         "bf16": dict(logp=1.4e-1, prob_rtol=1.3e-1, value=4.8e-3)},   # observed 7.1e-2 / 6.5e-2 / 2.4e-3
+    20: {"f32": dict(logp=3.8e-5, prob_rtol=3.7e-5, value=1.3e-6),     # observed 1.9e-5 / 1.8e-5 / 6.4e-7
+         "f16": dict(logp=5.4e-2, prob_rtol=5.3e-2, value=1.8e-3),     # observed 2.7e-2 / 2.7e-2 / 9.1e-4
+         "bf16": dict(logp=3.9e-1, prob_rtol=3.6e-1, value=1.4e-2)},   # observed 1.9e-1 / 1.8e-1 / 7.0e-3
 }
+TOL = TOL_BY_DEPTH[6]
+
+
+def tol_for(dtype, residuals):
+    return TOL_BY_DEPTH[6 if residuals <= 6 else (10 if residuals <= 10 else 20)][dtype]
 
 
 def compare(key, dtype, got, want, tol=None):
@@ -403,6 +417,171 @@ def test_concurrent_infer_threads():
         assert np.array_equal(g[0], w[0]) and np.array_equal(g[1], w[1])
 
 
+# ------------------------------------------------------------------------------ submit / wait, coalescing queue
+def _legal_case(n, seed):
+    rng = np.random.default_rng(seed)
+    boards = random_boards(n, seed)
+    nact = rng.integers(0, 40, n)
+    offs = np.concatenate([[0], np.cumsum(nact)]).astype(np.int32)
+    acts = rng.integers(0, 4672, int(offs[-1])).astype(np.int32)
+    return boards, offs, acts
+
+
+@pytest.mark.parametrize("dtype,C", [("bf16", 64), ("f32", 16), ("bf16", 96)])
+def test_submit_wait_equals_the_synchronous_calls(dtype, C):
+    """kh_submit_* / kh_wait: several small batches queued from one thread and evaluated merged give every caller the
+    bits its own synchronous call gives (rows do not interact, nn.cpp:59-91) — for planes -> policy + the reference's
+    flat value copy-out (nn.cpp:186, which depends on the CALLER's batch, not the merged one) and for records -> legal
+    priors; on the whole-network kernel, the fp32 path and the per-layer path."""
+    F, R = 30, 2
+    nn = NN(8, 8, F, 4672, filters=C, residuals=R, dtype=dtype)
+    nn.load_weights(W.random_weights(F, C, R, seed=3, peaky=10.0), 1)
+    xs = [np.random.default_rng(i).random((b, 8, 8, F), dtype=np.float32) for i, b in enumerate((1, 16, 5, 128, 33))]
+    want = [nn.infer(x) for x in xs]
+    nn.set_coalesce(1024, 20000)                      # hold the launch until all five are queued: one merged launch
+    tickets = [nn.submit_infer(x) for x in xs]
+    nn.set_coalesce(0, 0)
+    got = [t.wait() for t in tickets]
+    for (p, v), (wp, wv) in zip(got, want):
+        assert np.array_equal(p, wp) and np.array_equal(v, wv)
+    launches, rows = nn.coalesce_stats()
+    assert rows == sum(len(x) for x in xs) and launches <= 2
+    cases = [_legal_case(n, 10 + n) for n in (7, 64, 1, 200)]
+    want = [nn.infer_legal(*c) for c in cases]
+    for mode in (L.KH_VALUE_REFERENCE_FLAT, L.KH_VALUE_PER_SAMPLE0):
+        eng = nn if mode == L.KH_VALUE_REFERENCE_FLAT else NN(8, 8, F, 4672, filters=C, residuals=R, dtype=dtype, value_mode=mode)
+        if eng is not nn:
+            eng.load_weights(nn.get_weights(), 1)
+            want = [eng.infer_legal(*c) for c in cases]
+        eng.set_coalesce(1024, 20000)
+        tickets = [eng.submit_infer_legal(*c) for c in cases]
+        eng.set_coalesce(0, 0)
+        for t, (wp, wv) in zip(tickets, want):
+            p, v = t.wait()
+            assert np.array_equal(p, wp) and np.array_equal(v, wv)
+
+
+def test_submit_never_blocks_on_the_callers_own_tickets():
+    """Round 1's recorded hang (33 submits from one thread without a wait never returned: every call slot was leased
+    to the caller itself, and the 33rd waited for one of them).  Here tickets are a fixed pool: KH_MAX_OUTSTANDING
+    un-waited submissions are accepted, one more returns KH_ERR_INVALID at once, and after the waits the queue is
+    usable again.  A ticket cannot be waited for twice."""
+    F, C, R = 30, 32, 1
+    nn = NN(8, 8, F, 4672, filters=C, residuals=R, dtype="bf16")
+    nn.load_weights(W.random_weights(F, C, R, seed=3, peaky=10.0), 1)
+    x = np.random.default_rng(0).random((4, 8, 8, F), dtype=np.float32)
+    want = nn.infer(x)
+    tickets = [nn.submit_infer(x) for _ in range(L.KH_MAX_OUTSTANDING)]
+    with pytest.raises(KamiError) as ei:
+        nn.submit_infer(x)
+    assert ei.value.status == L.KH_ERR_INVALID and "outstanding" in str(ei.value)
+    for t in tickets:
+        p, v = t.wait()
+        assert np.array_equal(p, want[0]) and np.array_equal(v, want[1])
+    with pytest.raises(KamiError):
+        tickets[0].wait()
+    p, v = nn.submit_infer(x).wait()
+    assert np.array_equal(p, want[0])
+
+
+def test_queue_attributes_nan_to_the_submission_that_holds_it():
+    F, C, R = 30, 64, 1
+    nn = NN(8, 8, F, 4672, filters=C, residuals=R, dtype="bf16")
+    nn.load_weights(W.random_weights(F, C, R, seed=3), 1)
+    good = np.random.default_rng(0).random((6, 8, 8, F), dtype=np.float32)
+    bad = good.copy(); bad[3, 1, 1, 2] = np.nan
+    want = nn.infer(good)
+    nn.set_coalesce(1024, 20000)
+    t1, t2, t3 = nn.submit_infer(good), nn.submit_infer(bad), nn.submit_infer(good)
+    nn.set_coalesce(0, 0)
+    assert np.array_equal(t1.wait()[0], want[0])
+    with pytest.raises(KamiError) as ei:
+        t2.wait()
+    assert ei.value.status == L.KH_ERR_NAN_POLICY and str(ei.value) == "inference policy output contains NaN"
+    assert np.array_equal(t3.wait()[0], want[0])
+
+
+def test_concurrent_small_callers_are_coalesced():
+    """selfplay.cpp:196 from several inference threads at kami's default batch of 16: the synchronous kh_infer calls that
+    are inside the engine together are merged into common launches; every caller still gets its own rows' bits."""
+    import threading
+    F, C, R = 30, 64, 2
+    nn = NN(8, 8, F, 4672, filters=C, residuals=R, dtype="bf16")
+    nn.load_weights(W.random_weights(F, C, R, seed=4, peaky=10.0), 1)
+    xs = [np.random.default_rng(i).random((16, 8, 8, F), dtype=np.float32) for i in range(6)]
+    want = [nn.infer(x) for x in xs]
+    bad = []
+    calls = 40
+
+    def work(i):
+        for _ in range(calls):
+            p, v = nn.infer(xs[i])
+            if not (np.array_equal(p, want[i][0]) and np.array_equal(v, want[i][1])):
+                bad.append(i)
+
+    th = [threading.Thread(target=work, args=(i,)) for i in range(len(xs))]
+    [t.start() for t in th]
+    [t.join() for t in th]
+    assert not bad
+    launches, rows = nn.coalesce_stats()
+    assert rows > 0 and rows / launches > 16, (launches, rows)          # launches held more than one caller's batch
+
+
+def test_weight_swap_while_threads_infer():
+    """nn.cpp:166,206: read() replaces the weights while inference threads are inside infer().  Here the swap is atomic
+    and never stalls a caller: six threads keep calling (directly and through the queue) while the main thread swaps
+    between two parameter sets; every result must be exactly one set's output, never a mixture."""
+    import threading
+    F, C, R = 30, 64, 2
+    nn = NN(8, 8, F, 4672, filters=C, residuals=R, dtype="bf16")
+    blobs = [W.random_weights(F, C, R, seed=s, peaky=10.0) for s in (1, 2)]
+    xs = [np.random.default_rng(i).random((8 + 24 * (i % 2), 8, 8, F), dtype=np.float32) for i in range(6)]
+    want = []
+    for b in blobs:
+        nn.load_weights(b, 1)
+        want.append([nn.infer(x) for x in xs])
+    stop = threading.Event()
+    bad, seen = [], [set() for _ in xs]
+
+    def work(i):
+        while not stop.is_set():
+            p, v = nn.infer(xs[i])
+            k = [j for j in (0, 1) if np.array_equal(p, want[j][i][0]) and np.array_equal(v, want[j][i][1])]
+            if not k:
+                bad.append(i)
+            else:
+                seen[i].add(k[0])
+
+    th = [threading.Thread(target=work, args=(i,)) for i in range(len(xs))]
+    [t.start() for t in th]
+    for g in range(60):
+        nn.load_weights(blobs[g & 1], g + 2)
+    stop.set()
+    [t.join() for t in th]
+    assert not bad
+    assert nn.get_generation() == 61 and all(len(s) == 2 for s in seen)      # every thread saw both generations
+
+
+def test_selfplay_pool_pipelined_through_the_queue():
+    """The pool with two halves of every worker's trees in flight (kh_submit_encode_infer_legal / kh_wait) and the
+    engine merging the workers' submissions: BASELINE configs[1]'s shape (256 games, two leaves per tree = 512 positions
+    in flight), four workers; launches hold several workers' leaves."""
+    from kami_amd import search as S
+    F, C, R = 30, 64, 6
+    nn = NN(8, 8, F, 4672, filters=C, residuals=R, dtype="bf16", value_mode=L.KH_VALUE_PER_SAMPLE0)
+    nn.load_weights(W.random_weights(F, C, R, seed=5, peaky=5.0), 1)
+    pool = S.Pool(nn, games=256, threads=4, nodes=64, leaves_per_tree=2, seed=12, pipeline=True, coalesce_target=512, coalesce_wait_us=300)
+    st = pool.run(min_evals=200000, max_seconds=20.0)
+    assert st.evals >= 200000 and st.moves > st.evals // 80
+    launches, rows = nn.coalesce_stats()
+    assert rows == st.evals and rows / launches > 64 * 1.5, (launches, rows)     # a worker's half is 64 leaves
+    recs = pool.drain()
+    assert st.records == len(recs) and st.games_finished == st.white_wins + st.black_wins + st.draws
+    for r in recs[:100]:
+        v = np.array(r.visits[:r.nact])
+        assert 0 < r.nact <= S.MAX_RECORD_ACTIONS and abs(v.sum() - 1.0) < 1e-3
+
+
 def test_bench_two_ranks_control_flow(tmp_path):
     """bench.py under torch.distributed.run with 2 ranks (sharing this box's single GPU over gloo:
     RCCL refuses duplicate devices): barrier, max-over-ranks and the whole-job aggregate."""
@@ -654,14 +833,15 @@ def test_full_size_properties_wide_configs(name, dtype, F, C, R, B):
     # rows against the oracle (fp32 CPU restatement of the reference, pinned by the reference's fixtures)
     rows = [0, 1, B // 2 - 1, B // 2, B - 1]
     want = ko.forward(blob, F, C, R, x[rows])
-    compare(f"full/{name}_rows_vs_oracle", dtype, (p[rows], vf[rows], lg[rows]), want)
+    compare(f"full/{name}_rows_vs_oracle", dtype, (p[rows], vf[rows], lg[rows]), want, tol_for(dtype, R))
     # and the engine's exact-fp32 arithmetic on 64 rows (fp32 MFMA path up to 128 filters, fp32 VALU kernels beyond)
-    sub = np.linspace(0, B - 1, 64).astype(int)
+    sub = np.unique(np.concatenate([rows, np.linspace(0, B - 1, 60).astype(int)]))
     nf = NN(8, 8, F, 4672, filters=C, residuals=R, dtype="f32")
     nf.load_weights(blob, 1)
     fp, fvf, flg = nf.infer_full(x[sub])
-    compare(f"full/{name}_rows_vs_oracle", "f32", (fp[:2], fvf[:2], flg[:2]), tuple(w[:2] for w in want))
-    compare(f"full/{name}_64rows_vs_f32", dtype, (p[sub], vf[sub], lg[sub]), (fp, fvf, flg))
+    at = np.searchsorted(sub, rows)
+    compare(f"full/{name}_rows_vs_oracle", "f32", (fp[at], fvf[at], flg[at]), want, tol_for("f32", R))
+    compare(f"full/{name}_64rows_vs_f32", dtype, (p[sub], vf[sub], lg[sub]), (fp, fvf, flg), tol_for(dtype, R))
 
 
 def test_selfplay_pool_literal_configs1_shape():
