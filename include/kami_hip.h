@@ -196,7 +196,8 @@ int  kh_submit_encode_infer_legal(kh_engine* e, const kh_board* boards, int batc
 int  kh_wait(kh_engine* e, int64_t ticket);
 /* Launch policy of the queue.  target_batch 0 (default): whatever has accumulated goes as soon as a launch lane is
  * free.  target_batch > 0: a batch waits until it holds that many positions, but at most max_wait_us after its first
- * submission — for callers that know how many positions they keep in flight (the self-play pool). */
+ * submission and no longer than max_wait_us / 8 after its latest one (the burst has ended) — for callers that know how
+ * many positions they keep in flight (the self-play pool). */
 int  kh_set_coalesce(kh_engine* e, int target_batch, int max_wait_us);
 /* launches made by the queue so far and the positions they held (mean coalesced batch = rows / launches) */
 int  kh_coalesce_stats(kh_engine* e, int64_t* launches, int64_t* rows);

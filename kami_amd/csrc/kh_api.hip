@@ -7,6 +7,7 @@
 #include "kh_internal.h"
 #include "torch_archive.h"
 
+#include <sched.h>
 #include <atomic>
 #include <chrono>
 #include <thread>
@@ -725,7 +726,7 @@ constexpr int CO_LANES = 2;
 
 struct CoTicket {
     uint32_t serial = 0;
-    int state = 0;                              // 0 free, 1 queued, 2 done
+    std::atomic<int> state{ 0 };                // 0 free, 1 queued, 2 done (waiters spin on it, then sleep)
     int status = KH_OK;
     std::string err;
     int kind = 0, row0 = 0, rows = 0, act0 = 0, nact = 0;
@@ -740,11 +741,18 @@ struct CoBatch {
     int kind = 0;                               // 0: records + legal actions -> priors; 1: planes -> full policy rows
     int rows = 0, nact = 0, copying = 0;
     bool full = false;
-    std::chrono::steady_clock::time_point first;
+    std::chrono::steady_clock::time_point first, last;     // first / latest submission into this batch
     std::vector<CoTicket*> tickets;
-    std::vector<kh_board> boards;
-    std::vector<int32_t> offsets, actions;
-    std::vector<float> planes, priors, values, vfull, policy;
+    // kind 0 merges straight into page-locked memory that the kernels read and write THEMSELVES (no copy engine on
+    // the path: 100 KB each way per launch is latency, not bandwidth): boards | offsets | actions in, priors | values
+    // | NaN flags out
+    PinMem pin_in, pin_out;
+    kh_board* boards = nullptr;
+    int32_t *offsets = nullptr, *actions = nullptr;
+    float *priors = nullptr, *values = nullptr;
+    int* flags_out = nullptr;
+    Slot slot;                                  // stream + device scratch of this buffer's launches
+    std::vector<float> planes, vfull, policy;   // kind 1 / reference value copy-out: plain host staging for infer_host
 };
 
 struct Coalescer {
@@ -754,10 +762,48 @@ struct Coalescer {
     CoTicket tickets[KH_MAX_OUTSTANDING];
     CoBatch batches[CO_BUFFERS];
     std::thread lanes[CO_LANES];
-    int lanes_busy = 0;
+    int lanes_busy = 0, sleepers = 0;
+    int spin_us = 150;                          // kh_wait spins this long on its ticket before it sleeps (KAMI_WAIT_SPIN_US)
     bool stop = false;
     int64_t launches = 0, rows_launched = 0;
+    // KAMI_CO_TRACE=1: where a coalesced launch's time goes (printed when the engine is destroyed)
+    bool trace = false;
+    double us_fill = 0, us_copywait = 0, us_run = 0, us_finish = 0;
 };
+
+// records + legal actions -> priors + one value per position, straight out of / into the batch's page-locked blocks:
+// forward kernel(s) and the gather kernel on the buffer's own stream, completion polled (hipStreamQuery) instead of a
+// blocking wait — the launch's latency is what every waiting caller pays.
+int co_run_legal_direct(kh_engine* e, CoBatch& b)
+{
+    const int B = b.rows;
+    std::shared_ptr<Weights> W = current_weights(e);
+    if (!W) return fail(KH_ERR_NO_WEIGHTS, "kh_infer before kh_load_weights");
+    int rc = set_device(e);
+    if (rc) return rc;
+    Slot& s = b.slot;
+    if ((rc = slot_ensure(e, s, B, true))) return rc;
+    hipStream_t st = s.stream;
+    if (fused_ingest(e, *W)) rc = forward_tower(e, *W, s, nullptr, B, s.policy.as<float>(), s.vfull.as<float>(), nullptr, b.boards);
+    else {
+        kh::launch_encode_f32(b.boards, B, s.planes.as<float>(), st);
+        rc = forward_dispatch(e, *W, s, s.planes.as<float>(), B, s.policy.as<float>(), s.vfull.as<float>(), nullptr);
+    }
+    if (rc) return rc;
+    kh::launch_gather_legal(s.policy.as<float>(), b.offsets, b.actions, b.priors, B, st, s.vfull.as<float>(), KH_VALUE_WIDTH, b.values,
+                            s.flags.as<int>(), b.flags_out);
+    HIPCHK(hipGetLastError());
+    for (;;) {
+        const hipError_t q = hipStreamQuery(st);
+        if (q == hipSuccess) break;
+        if (q != hipErrorNotReady) return fail(KH_ERR_HIP, "hipStreamQuery failed: %s", hipGetErrorString(q));
+        sched_yield();                          // the callers' threads may need this core: poll, but never hog
+    }
+    if (b.flags_out[0] | b.flags_out[1]) s.flags_clean = false;
+    if (b.flags_out[0]) return fail(KH_ERR_NAN_POLICY, "inference policy output contains NaN");   // nn.cpp:176-177
+    if (b.flags_out[1]) return fail(KH_ERR_NAN_VALUE, "inference value output contains NaN");     // nn.cpp:179-180
+    return KH_OK;
+}
 
 void co_run_batch(kh_engine* e, CoBatch& b)
 {
@@ -765,16 +811,14 @@ void co_run_batch(kh_engine* e, CoBatch& b)
     int rc;
     const bool flat = e->cfg.value_mode == KH_VALUE_REFERENCE_FLAT;
     if (b.kind == 0) {
-        b.priors.resize((size_t)std::max(b.nact, 1));
-        b.values.resize((size_t)B);
-        LegalIO l{ b.offsets.data(), b.actions.data(), b.priors.data() };
         if (flat) {
             // nn.cpp:186 hands back the first `batch` floats of the caller's OWN flattened [batch,256] tensor: take the
             // whole tensor and cut each caller's slice out of it below
+            LegalIO l{ b.offsets, b.actions, b.priors };
             b.vfull.resize((size_t)B * KH_VALUE_WIDTH);
-            rc = infer_host(e, nullptr, b.boards.data(), B, nullptr, nullptr, b.vfull.data(), nullptr, &l);
+            rc = infer_host(e, nullptr, b.boards, B, nullptr, nullptr, b.vfull.data(), nullptr, &l);
         } else {
-            rc = infer_host(e, nullptr, b.boards.data(), B, nullptr, b.values.data(), nullptr, nullptr, &l);
+            rc = co_run_legal_direct(e, b);
         }
     } else {
         b.policy.resize((size_t)B * KH_PSIZE);
@@ -798,11 +842,11 @@ void co_run_batch(kh_engine* e, CoBatch& b)
         t->status = rc; t->err = err;
         if (rc) continue;
         if (t->kind == 0) {
-            if (t->nact) memcpy(t->priors, b.priors.data() + t->act0, (size_t)t->nact * 4);
+            if (t->nact) memcpy(t->priors, b.priors + t->act0, (size_t)t->nact * 4);
         } else {
             memcpy(t->policy, b.policy.data() + (size_t)t->row0 * KH_PSIZE, (size_t)t->rows * KH_PSIZE * 4);
         }
-        if (b.kind == 0 && !flat) memcpy(t->value, b.values.data() + t->row0, (size_t)t->rows * 4);
+        if (b.kind == 0 && !flat) memcpy(t->value, b.values + t->row0, (size_t)t->rows * 4);
         else if (flat) memcpy(t->value, b.vfull.data() + (size_t)t->row0 * KH_VALUE_WIDTH, (size_t)t->rows * 4);    // rows <= 256 here
         else for (int i = 0; i < t->rows; ++i) t->value[i] = b.vfull[(size_t)(t->row0 + i) * KH_VALUE_WIDTH];
     }
@@ -819,10 +863,12 @@ void co_lane(Coalescer* c)
         for (auto& b : c->batches) {
             if (b.state != 1 || b.rows == 0) continue;
             // immediate mode (no target): whatever has accumulated goes as soon as a lane is free;
-            // target mode: wait for `target` rows, at most wait_us after the batch's first submission
+            // target mode: wait for `target` rows — but no longer than wait_us after the batch's first submission, and
+            // not once the burst of submissions has ended (nothing added for wait_us / 8: callers that keep a fixed
+            // number of positions in flight rarely hit the target exactly — terminal leaves need no evaluation)
             bool ready = b.full || target <= 0 || b.rows >= target;
             if (!ready) {
-                const auto due = b.first + std::chrono::microseconds(wait_us);
+                const auto due = std::min(b.first + std::chrono::microseconds(wait_us), b.last + std::chrono::microseconds(wait_us / 8 + 1));
                 if (std::chrono::steady_clock::now() >= due) ready = true;
                 else deadline = std::min(deadline, due);
             }
@@ -836,17 +882,25 @@ void co_lane(Coalescer* c)
         }
         take->state = 2;
         ++c->lanes_busy;
+        const auto t_seal = std::chrono::steady_clock::now();
         while (take->copying > 0) c->cv_lane.wait(lk);          // submitters still copying their rows in
         lk.unlock();
+        const auto t_run = std::chrono::steady_clock::now();
         co_run_batch(e, *take);
+        const auto t_ran = std::chrono::steady_clock::now();
         lk.lock();
         --c->lanes_busy;
         c->launches += 1; c->rows_launched += take->rows;
-        for (CoTicket* t : take->tickets) t->state = 2;
+        for (CoTicket* t : take->tickets) t->state.store(2, std::memory_order_release);
         take->tickets.clear();
         take->rows = take->nact = 0; take->full = false; take->state = 0;
-        c->cv_done.notify_all();
+        if (c->sleepers) c->cv_done.notify_all();
         c->cv_space.notify_all();
+        if (c->trace) {
+            auto us = [](std::chrono::steady_clock::duration d) { return std::chrono::duration<double, std::micro>(d).count(); };
+            c->us_fill += us(t_seal - take->first); c->us_copywait += us(t_run - t_seal); c->us_run += us(t_ran - t_run);
+            c->us_finish += us(std::chrono::steady_clock::now() - t_ran);
+        }
     }
 }
 
@@ -856,6 +910,8 @@ Coalescer* co_get(kh_engine* e)
     if (!e->co) {
         Coalescer* c = new Coalescer();
         c->e = e;
+        c->trace = getenv("KAMI_CO_TRACE") != nullptr;
+        if (getenv("KAMI_WAIT_SPIN_US")) c->spin_us = std::max(0, atoi(getenv("KAMI_WAIT_SPIN_US")));
         for (auto& l : c->lanes) l = std::thread(co_lane, c);
         e->co = c;
     }
@@ -869,6 +925,14 @@ void co_destroy(kh_engine* e)
     { std::lock_guard<std::mutex> lk(c->mu); c->stop = true; }
     c->cv_lane.notify_all();
     for (auto& l : c->lanes) if (l.joinable()) l.join();
+    (void)hipSetDevice(e->cfg.device);
+    for (auto& b : c->batches) {
+        if (b.slot.stream) { (void)hipStreamSynchronize(b.slot.stream); (void)hipStreamDestroy(b.slot.stream); b.slot.stream = nullptr; }
+    }
+    if (c->trace && c->launches)
+        fprintf(stderr, "[kami queue] %lld launches, %.1f rows each; per launch: filling %.1f us, waiting for copies %.1f us, "
+                "engine call %.1f us, hand-back %.1f us\n", (long long)c->launches, (double)c->rows_launched / c->launches,
+                c->us_fill / c->launches, c->us_copywait / c->launches, c->us_run / c->launches, c->us_finish / c->launches);
     delete c;
     e->co = nullptr;
 }
@@ -898,7 +962,7 @@ int co_submit(kh_engine* e, int kind, const kh_board* boards, const float* plane
     CoTicket* t = nullptr;
     int tid = 0;
     for (; tid < KH_MAX_OUTSTANDING; ++tid)
-        if (c->tickets[tid].state == 0) { t = &c->tickets[tid]; break; }
+        if (c->tickets[tid].state.load(std::memory_order_acquire) == 0) { t = &c->tickets[tid]; break; }
     if (!t) return fail(KH_ERR_INVALID, "%d submissions are outstanding on this engine: kh_wait for some before submitting more", KH_MAX_OUTSTANDING);
     CoBatch* b = nullptr;
     for (;;) {
@@ -913,16 +977,29 @@ int co_submit(kh_engine* e, int kind, const kh_board* boards, const float* plane
             if (x.state == 0) { b = &x; break; }
         if (b) {
             b->state = 1; b->kind = kind; b->rows = 0; b->nact = 0; b->full = false;
-            b->first = std::chrono::steady_clock::now();
+            b->first = b->last = std::chrono::steady_clock::now();
             if (kind == 0) {
-                if (b->boards.empty()) { b->boards.resize(CO_ROWS); b->offsets.resize(CO_ROWS + 1); b->actions.resize(CO_ACTS); }
+                if (!b->boards) {
+                    const size_t o_offs = (size_t)CO_ROWS * sizeof(kh_board), o_acts = o_offs + (((size_t)CO_ROWS + 1) * 4 + 15) / 16 * 16;
+                    const size_t o_vals = (size_t)CO_ACTS * 4, o_flags = o_vals + (size_t)CO_ROWS * 4;
+                    if (set_device(e) || b->pin_in.ensure(o_acts + (size_t)CO_ACTS * 4) || b->pin_out.ensure(o_flags + 16)) {
+                        b->state = 0;
+                        return KH_ERR_HIP;
+                    }
+                    b->boards = reinterpret_cast<kh_board*>(b->pin_in.at(0));
+                    b->offsets = reinterpret_cast<int32_t*>(b->pin_in.at(o_offs));
+                    b->actions = reinterpret_cast<int32_t*>(b->pin_in.at(o_acts));
+                    b->priors = reinterpret_cast<float*>(b->pin_out.at(0));
+                    b->values = reinterpret_cast<float*>(b->pin_out.at(o_vals));
+                    b->flags_out = reinterpret_cast<int*>(b->pin_out.at(o_flags));
+                }
                 b->offsets[0] = 0;
             } else if (b->planes.size() < (size_t)cap_rows * 64 * F) b->planes.resize((size_t)cap_rows * 64 * F);
             break;
         }
         c->cv_space.wait(lk);                                    // every buffer is on the device: one of them comes back
     }
-    t->state = 1; t->status = KH_OK; t->err.clear(); ++t->serial;
+    t->state.store(1, std::memory_order_relaxed); t->status = KH_OK; t->err.clear(); ++t->serial;
     t->kind = kind; t->row0 = b->rows; t->rows = batch; t->act0 = b->nact; t->nact = nact;
     t->boards = boards; t->planes = planes; t->offsets = offsets; t->actions = actions;
     t->priors = priors; t->value = value; t->policy = policy;
@@ -930,10 +1007,11 @@ int co_submit(kh_engine* e, int kind, const kh_board* boards, const float* plane
     b->tickets.push_back(t);
     ++b->copying;
     lk.unlock();
+    b->last = std::chrono::steady_clock::now();
     // this caller's rows into the merge buffers (every caller copies its own, in parallel)
     if (kind == 0) {
-        memcpy(b->boards.data() + t->row0, boards, (size_t)batch * sizeof(kh_board));
-        if (nact) memcpy(b->actions.data() + t->act0, actions, (size_t)nact * 4);
+        memcpy(b->boards + t->row0, boards, (size_t)batch * sizeof(kh_board));
+        if (nact) memcpy(b->actions + t->act0, actions, (size_t)nact * 4);
         for (int i = 1; i <= batch; ++i) b->offsets[t->row0 + i] = t->act0 + offsets[i];
     } else {
         memcpy(b->planes.data() + (size_t)t->row0 * 64 * F, planes, (size_t)batch * 64 * F * 4);
@@ -953,13 +1031,30 @@ int co_wait(kh_engine* e, int64_t ticket)
     const int tid = (int)(ticket & 0xffffffff);
     const uint32_t serial = (uint32_t)(ticket >> 32);
     if (tid < 0 || tid >= KH_MAX_OUTSTANDING) return fail(KH_ERR_INVALID, "no such ticket");
-    std::unique_lock<std::mutex> lk(c->mu);
     CoTicket& t = c->tickets[tid];
-    if (t.state == 0 || t.serial != serial) return fail(KH_ERR_INVALID, "ticket already waited for (or never issued)");
-    while (t.state != 2) c->cv_done.wait(lk);
+    if (t.state.load(std::memory_order_acquire) == 0 || t.serial != serial)
+        return fail(KH_ERR_INVALID, "ticket already waited for (or never issued)");
+    // a launch is ~100 us away at most: spin on the ticket first (no wake-up latency, no mutex convoy when a launch
+    // releases many callers at once), sleep on the condition variable only when it takes longer
+    if (t.state.load(std::memory_order_acquire) != 2 && c->spin_us > 0) {
+        const auto until = std::chrono::steady_clock::now() + std::chrono::microseconds(c->spin_us);
+        for (int k = 0; t.state.load(std::memory_order_acquire) != 2; ++k) {
+            __builtin_ia32_pause();
+            if ((k & 63) == 63) {
+                sched_yield();                  // lets a launch lane (or another caller) have the core if it needs one
+                if (std::chrono::steady_clock::now() >= until) break;
+            }
+        }
+    }
+    if (t.state.load(std::memory_order_acquire) != 2) {
+        std::unique_lock<std::mutex> lk(c->mu);
+        ++c->sleepers;
+        while (t.state.load(std::memory_order_acquire) != 2) c->cv_done.wait(lk);
+        --c->sleepers;
+    }
     const int rc = t.status;
     if (rc) g_err = t.err;
-    t.state = 0;
+    t.state.store(0, std::memory_order_release);
     return rc;
 }
 

@@ -8,13 +8,13 @@ F, C, R = 30, 64, 6
 nn = NN(8, 8, F, 4672, filters=C, residuals=R, dtype="bf16", value_mode=L.KH_VALUE_PER_SAMPLE0)
 nn.load_weights(W.random_weights(F, C, R, seed=1, peaky=5.0), 1)
 CASES = [  # games, threads, leaves/tree, visits/move, pipeline, coalesce target, wait us
-    # BASELINE configs[1] literally: 256 games, 800 sims/move, batch-512 eval (two leaves of every tree in flight)
-    (256, 1, 2, 800, 0, 0, 0), (256, 4, 2, 800, 0, 0, 0),
-    (256, 8, 2, 800, 1, 512, 200), (256, 16, 2, 800, 1, 512, 200), (256, 16, 2, 800, 1, 256, 100), (256, 16, 2, 800, 1, 0, 0),
-    # ... and with four leaves per tree: two batch-512 evaluations in flight
-    (256, 8, 4, 800, 1, 512, 200), (256, 16, 4, 800, 1, 512, 200),
+    # BASELINE configs[1] literally: 256 games, 800 sims/move, batch-512 eval
+    (256, 1, 2, 800, 0, 0, 0), (256, 4, 2, 800, 0, 0, 0),                       # blocking calls (round 1's schedule)
+    (256, 14, 2, 800, 1, 512, 200), (256, 14, 2, 800, 1, 512, 80),               # 512 positions in flight, queue + 2 launch lanes
+    (256, 14, 4, 800, 1, 512, 200), (256, 14, 4, 800, 1, 512, 80), (256, 8, 4, 800, 1, 512, 80),   # 1024 in flight: two batch-512 evaluations
+    (256, 14, 8, 800, 1, 512, 80),
     # many trees, one leaf each (the reference's schedule, more games)
-    (4096, 16, 1, 64, 0, 0, 0), (8192, 16, 1, 64, 0, 0, 0), (8192, 16, 1, 64, 1, 1024, 200), (4096, 16, 2, 64, 1, 1024, 200),
+    (8192, 16, 1, 64, 0, 0, 0), (8192, 14, 1, 64, 1, 1024, 100), (4096, 14, 2, 64, 1, 1024, 100),
 ]
 if len(sys.argv) > 1:
     CASES = CASES[:int(sys.argv[1])]
