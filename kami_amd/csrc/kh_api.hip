@@ -129,7 +129,8 @@ struct Weights {
     std::string tw_why;
     // per-layer MFMA path for wide nets (layers_mfma.hip)
     DevMem ly_w, ly_shift, ly_misc;      // ly_misc: vw[CP], fcw[256*64], fcb[256]
-    std::vector<size_t> ly_w_off, ly_shift_off;
+    DevMem ly_w4;                        // 3x3 layers once more, packed for conv4_mfma_kernel
+    std::vector<size_t> ly_w_off, ly_shift_off, ly_w4_off;
     int ly_FP = 0, ly_CP = 0;
     float ly_vshift = 0.0f;
     bool ly_ok = false;
@@ -216,6 +217,28 @@ void pack_layer_generic(std::vector<uint16_t>& out, int dtype, const float* w, c
                         }
 }
 
+// The same fragments for conv4_mfma_kernel (four boards x 128 output channels per workgroup): 8 KB chunks of 32 input
+// channels x 128 output channels, [Co/128][Ci/64][tap][half][ks2][ms 0..3][lane][8] — the reduction walks in the same
+// order as above (64-channel slices, then taps, then k-steps), so both kernels produce the same bits.
+void pack_layer_wide128(std::vector<uint16_t>& out, int dtype, const float* w, const float* scale,
+                        int Co, int Ci, int taps, int CoP, int CiP)
+{
+    for (int cb = 0; cb < CoP / 128; ++cb)
+        for (int slice = 0; slice < CiP / 64; ++slice)
+            for (int tap = 0; tap < taps; ++tap)
+                for (int kk = 0; kk < 4; ++kk)                  // kk = 2 * half + ks2
+                    for (int ms = 0; ms < 4; ++ms)
+                        for (int l = 0; l < 64; ++l) {
+                            const int r = l & 31, h = l >> 5, ks = slice * 4 + kk;
+                            for (int j = 0; j < 8; ++j) {
+                                const int co = cb * 128 + ms * 32 + r, ci = ks * 16 + 8 * h + j;
+                                float v = 0.0f;
+                                if (co < Co && ci < Ci) v = w[((size_t)co * Ci + ci) * taps + tap] * (scale ? scale[co] : 1.0f);
+                                out.push_back(dtype == KH_BF16 ? f2bf16(v) : f2f16(v));
+                            }
+                        }
+}
+
 // fp32 fragments for conv_f32_kernel: [Co/64][tap][Ci/8][2][lane][4]; lane (r, h) holds
 // W[co = ms*32 + r][ci = 8j + 4h + 0..3]
 void pack_layer_f32(std::vector<float>& out, const float* w, const float* scale, int Co, int Ci, int taps, int CoP, int CiP)
@@ -240,17 +263,24 @@ int build_layers(Weights& W, const HostNet& n, int dtype, int F, int C, int R)
     const int FP = f32 ? (F + 7) / 8 * 8 : (F + 63) / 64 * 64, CP = (C + 63) / 64 * 64;
     // LDS image of two boards: 2 x 120 x (Ci * elem + 16) bytes must fit 160 KB
     if (f32 ? (CP > 128 || FP > 128) : (CP > 256 || FP > 256)) return KH_OK;      // not covered: ly_ok stays false
-    std::vector<uint16_t> w;
+    std::vector<uint16_t> w, w4;
     std::vector<float> wf;
     std::vector<float> shift;
     std::vector<float> sc(256), sh(256);
     auto add = [&](const float* wt, const ConvBN* bn, const float* bias, int Co, int Ci, int taps, int CoP, int CiP) {
         W.ly_w_off.push_back(w.size());
         W.ly_shift_off.push_back(shift.size());
+        W.ly_w4_off.push_back((size_t)-1);
         if (bn) fold_bn(*bn, Co, sc.data(), sh.data());
         else for (int i = 0; i < Co; ++i) { sc[i] = 1.0f; sh[i] = bias[i]; }
         if (f32) { W.ly_w_off.back() = wf.size(); pack_layer_f32(wf, wt, sc.data(), Co, Ci, taps, CoP, CiP); }
-        else pack_layer_generic(w, dtype, wt, sc.data(), Co, Ci, taps, CoP, CiP);
+        else {
+            pack_layer_generic(w, dtype, wt, sc.data(), Co, Ci, taps, CoP, CiP);
+            if (taps == 9 && CoP % 128 == 0 && (CiP == 128 || CiP == 256)) {     // conv4_mfma_kernel's shapes
+                W.ly_w4_off.back() = w4.size();
+                pack_layer_wide128(w4, dtype, wt, sc.data(), Co, Ci, taps, CoP, CiP);
+            }
+        }
         for (int i = 0; i < CoP; ++i) shift.push_back(i < Co ? sh[i] : 0.0f);
     };
     add(n.stem.w, &n.stem, nullptr, C, F, 9, CP, FP);
@@ -268,6 +298,10 @@ int build_layers(Weights& W, const HostNet& n, int dtype, int F, int C, int R)
     const size_t wbytes = f32 ? wf.size() * 4 : w.size() * 2;
     if (W.ly_w.ensure(wbytes) || W.ly_shift.ensure(shift.size() * 4) || W.ly_misc.ensure(misc.size() * 4)) return KH_ERR_HIP;
     HIPCHK(hipMemcpy(W.ly_w.p, wsrc, wbytes, hipMemcpyHostToDevice));
+    if (!w4.empty()) {
+        if (W.ly_w4.ensure(w4.size() * 2)) return KH_ERR_HIP;
+        HIPCHK(hipMemcpy(W.ly_w4.p, w4.data(), w4.size() * 2, hipMemcpyHostToDevice));
+    }
     HIPCHK(hipMemcpy(W.ly_shift.p, shift.data(), shift.size() * 4, hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(W.ly_misc.p, misc.data(), misc.size() * 4, hipMemcpyHostToDevice));
     W.ly_ok = true;
@@ -550,6 +584,7 @@ int forward_layers(kh_engine* e, const Weights& W, Slot& s, const float* d_in, i
     L.logits = d_logits_out ? d_logits_out : s.logits.as<float>();
     L.v64 = s.v64.as<float>();
     L.w = W.ly_w.as<unsigned short>(); L.w_off = W.ly_w_off.data();
+    L.w4 = W.ly_w4.as<unsigned short>(); L.w4_off = W.ly_w4_off.data();
     L.shift = W.ly_shift.as<float>(); L.shift_off = W.ly_shift_off.data();
     L.vw = W.ly_misc.as<float>(); L.vshift = W.ly_vshift;
     HIPCHK(kh::launch_layers(e->cfg.dtype, L, st));

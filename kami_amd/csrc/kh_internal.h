@@ -76,6 +76,8 @@ struct LayersArgs {
     float* v64;                    // [B][64]
     const unsigned short* w;       // packed fragments of all layers (device)
     const size_t* w_off;           // HOST array: element offset of each layer in w
+    const unsigned short* w4;      // 3x3 layers packed for conv4_mfma_kernel (device; nullptr when no layer is eligible)
+    const size_t* w4_off;          // HOST array: element offset of each layer in w4, (size_t)-1 = not eligible
     const float* shift;            // folded shifts of all layers (device)
     const size_t* shift_off;       // HOST array: float offset of each layer in shift
     const float* vw;               // [CP] valueconv weight * bn scale (device)

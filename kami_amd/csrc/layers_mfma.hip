@@ -87,6 +87,7 @@ struct ConvArgs {
     const unsigned short* in;     // T [B][64][Ci]
     const unsigned short* w;      // packed fragments [Co/64][taps][Ci/16][2][64 lanes][8]
     const float* shift;           // [Co] folded BatchNorm shift (or bias)
+    const unsigned short* w4;     // the same layer packed for conv4_mfma_kernel (nullptr: not eligible)
     const unsigned short* skip;   // T [B][64][Co] (EPI 1) or nullptr
     void* out;                    // T [B][64][Co] (EPI 0/1) or fp32 [B][4672] (EPI 2)
     int B, Ci, Co;                // Ci % 16 == 0, Co % 64 == 0
@@ -342,6 +343,366 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, RDN == 2
     WIDE_STAMP(5);
 }
 
+// ---------------------------------------------------------------------------------------------
+// conv4_mfma_kernel — 3x3 layers with 128 (or 2 x 128) input channels and >= 128 output channels, FOUR boards per
+// workgroup: each wave owns one whole board (64 pixels) x 128 output channels = 8 accumulators.
+//
+// Why: conv_mfma_kernel's 64-channel x 32-pixel wave tile needs 1.5 ds_read_b128 per MFMA (all four
+// waves re-read the same A fragments) and pulls the layer's weights through the CU once per 128 pixels: at the bf16
+// MFMA rate that is 192 B/clk of LDS reads (of 256) and 76 GB/s per CU of L2 -> LDS weight traffic (the L2 gives
+// ~70): the step ran 322 clocks for 8 MFMAs.  Here a k-step is 4 A + 2 B fragment reads for 8 MFMAs (0.75 per
+// MFMA, 96 B/clk) and the weights pass once per 256 pixels (38 GB/s per CU at peak).  The price is LDS: the four
+// boards' 128-channel images (130 560 B) + a 4-slot ring = 163 328 B, one workgroup per CU, so the epilogue goes
+// straight from registers to HBM (16-byte stores after a v_permlane32_swap of packed pairs, no transpose tile).
+// Same reduction order as conv_mfma_kernel (64-channel slices outermost, then taps, then k-steps), same fp32
+// epilogue: the two kernels agree bit for bit and the launcher picks per call.
+// Weights: pack_layer_wide128 (kh_api.hip): [Co/128][Ci/64][tap][half][ks2][ms 0..3][lane][8], 8 KB chunks.
+template <typename T, int EPI, int NP>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void conv4_mfma_kernel(ConvArgs a)
+{
+    constexpr int RDN = 4, TAPS = 9;
+    constexpr int LDS_IMG = RDN * CHUNKB;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    using V = typename Elem<T>::vec8;
+    const int tid = threadIdx.x, lane = tid & 63, h = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    constexpr int Ci = 128, CiTot = NP * Ci;
+    const int Co = a.Co;
+    constexpr int stride = Ci * 2 + 16;                    // 272 B per pixel: 17 16-byte slots, odd
+    constexpr int board_bytes = NPIX * stride;
+    const int b0 = blockIdx.x * 4, cb = blockIdx.y;
+    constexpr int NCH = 2 * 9 * 2, NCHT = NP * NCH;        // 8 KB chunks per pass: 2 slices x 9 taps x 2 halves of 2 k-steps
+    const char* stream = reinterpret_cast<const char*>(a.w) + (size_t)cb * NCHT * CHUNKB;
+    char* img = smem + LDS_IMG;
+    WIDE_STAMP(0);
+    WIDE_STAMP(7);
+
+#pragma unroll
+    for (int i = 0; i < RDN - 1; ++i) ring_issue<RDN>(stream, NCHT, i, wave, lane);
+
+    {   // zero halo of the four images (staging only ever writes interior pixels)
+        const u32x4 z = { 0, 0, 0, 0 };
+        constexpr int per_px = stride / 16;
+        for (int i = tid; i < 4 * NPIX; i += 256) {
+            const int pp = i % NPIX, yy = pp / PITCH, xx = pp % PITCH;
+            if (yy >= 1 && yy <= 8 && xx >= 1 && xx <= 8) continue;
+            char* d = img + (i / NPIX) * board_bytes + pp * stride;
+            for (int k = 0; k < per_px; ++k) *reinterpret_cast<u32x4*>(d + k * 16) = z;
+        }
+    }
+    // the four boards' channels [pass * 128, +128): 4096 16-byte pieces, 16 per thread, all in flight at once
+    auto stage = [&](int pass) {
+        const unsigned short* src = a.in + pass * Ci;
+        u32x4 v[16];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) {
+            const int i = tid + u * 256;
+            const int bb = i >> 10, p = (i >> 4) & 63, c = i & 15;
+            v[u] = u32x4{ 0, 0, 0, 0 };
+            if (b0 + bb < a.B) v[u] = *reinterpret_cast<const u32x4*>(src + ((size_t)(b0 + bb) * 64 + p) * CiTot + c * 8);
+        }
+#pragma unroll
+        for (int u = 0; u < 16; ++u) {
+            const int i = tid + u * 256;
+            const int bb = i >> 10, p = (i >> 4) & 63, c = i & 15;
+            const int pix = ((p >> 3) + 1) * PITCH + (p & 7) + 1;
+            *reinterpret_cast<u32x4*>(img + bb * board_bytes + pix * stride + c * 16) = v[u];
+        }
+    };
+
+    // this wave: board `wave`, both 32-pixel halves (rows 0-3 / 4-7), 128 channels of block cb
+    const int lp = PIXMAP[lane & 31];
+    const int py = lp >> 3, px = lp & 7;
+    const unsigned b_base = LDS_IMG + wave * board_bytes + (py * PITCH + px) * stride + h * 16;
+    constexpr unsigned HALF = 4 * PITCH * stride;          // second pixel half: four image rows further
+    f32x16 acc[8];                                         // [ms * 2 + hp]
+#pragma unroll
+    for (int ms = 0; ms < 4; ++ms)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const float4 s = *reinterpret_cast<const float4*>(a.shift + cb * 128 + ms * 32 + 8 * g + 4 * h);
+#pragma unroll
+            for (int hp = 0; hp < 2; ++hp) {
+                acc[ms * 2 + hp][4 * g + 0] = s.x; acc[ms * 2 + hp][4 * g + 1] = s.y;
+                acc[ms * 2 + hp][4 * g + 2] = s.z; acc[ms * 2 + hp][4 * g + 3] = s.w;
+            }
+        }
+    // chunk n of a pass: slice q = n / 18, tap = (n % 18) / 2, half = n & 1 (k-steps 2 * half, 2 * half + 1 of the slice)
+    auto chunk_off = [](int n) -> unsigned {
+        const int q = n / 18, tap = (n % 18) >> 1, half = n & 1;
+        return (unsigned)(((tap / 3) * PITCH + (tap % 3)) * stride) + q * 128 + half * 64;
+    };
+    V A[2][8], Bq[2][4];                                   // A[.][ks2 * 4 + ms], Bq[.][ks2 * 2 + hp]
+#pragma unroll
+    for (int pass = 0; pass < NP; ++pass) {
+        if (pass > 0) __syncthreads();                     // everybody is done reading the previous pass's image
+        stage(pass);
+        if (pass == 0) WIDE_STAMP(1);
+        asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(2 * (RDN - 2)) : "memory");
+        if (pass == 0) WIDE_STAMP(2);
+        {
+            const unsigned a_off = (unsigned)(((pass * NCH) % RDN) * CHUNKB) + lane * 16;
+#pragma unroll
+            for (int f = 0; f < 8; ++f) A[0][f] = *reinterpret_cast<const V*>(smem + a_off + f * 1024);
+#pragma unroll
+            for (int k = 0; k < 2; ++k)
+#pragma unroll
+                for (int hp = 0; hp < 2; ++hp) Bq[0][k * 2 + hp] = *reinterpret_cast<const V*>(smem + b_base + hp * HALF + chunk_off(0) + k * 32);
+        }
+#pragma unroll
+        for (int n = 0; n < NCH; ++n) {
+            const int cur = n & 1, nxt = cur ^ 1, g = pass * NCH + n;
+            asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(2 * (RDN - 3)) : "memory");
+            __builtin_amdgcn_sched_barrier(0);
+            ring_issue<RDN>(stream, NCHT, g + RDN - 1, wave, lane);
+            const unsigned a_off = (unsigned)(((g + 1) % RDN) * CHUNKB) + lane * 16;
+#pragma unroll
+            for (int f = 0; f < 8; ++f) A[nxt][f] = *reinterpret_cast<const V*>(smem + a_off + f * 1024);
+            if (n + 1 < NCH) {
+#pragma unroll
+                for (int k = 0; k < 2; ++k)
+#pragma unroll
+                    for (int hp = 0; hp < 2; ++hp) Bq[nxt][k * 2 + hp] = *reinterpret_cast<const V*>(smem + b_base + hp * HALF + chunk_off(n + 1) + k * 32);
+            }
+#pragma unroll
+            for (int k = 0; k < 2; ++k)
+#pragma unroll
+                for (int ms = 0; ms < 4; ++ms)
+#pragma unroll
+                    for (int hp = 0; hp < 2; ++hp) acc[ms * 2 + hp] = Elem<T>::mfma(A[cur][k * 4 + ms], Bq[cur][k * 2 + hp], acc[ms * 2 + hp]);
+#pragma unroll
+            for (int i = 0; i < 12; ++i) {                  // one operand read per MFMA gap, the last four gaps free
+                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            }
+            __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+        }
+    }
+    WIDE_STAMP(3);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // drain the ring (tail re-fetches) before exit
+    WIDE_STAMP(4);
+
+    // ---- epilogue, registers -> HBM.  Lane (pixel, h) holds channels 32 ms + 8 g + 4 h + 0..3: after ReLU (+ skip, in
+    // fp32 like nn.cpp:31) and rounding, groups g = 2j / 2j + 1 are exchanged between the lane halves so that lane
+    // (pixel, h) owns the 8 consecutive channels 32 ms + 16 j + 8 h + 0..7: one 16-byte store.
+    const int b = b0 + wave;
+    if (b >= a.B) return;
+    unsigned short* outp = reinterpret_cast<unsigned short*>(a.out);
+#pragma unroll
+    for (int hp = 0; hp < 2; ++hp) {
+        const int pix = (4 * hp + py) * 8 + px;
+        const size_t row = ((size_t)b * 64 + pix) * Co + cb * 128;
+#pragma unroll
+        for (int ms = 0; ms < 4; ++ms) {
+            unsigned pk[4][2];
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                float v[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) v[i] = relu_keep_nan(acc[ms * 2 + hp][4 * g + i]);
+                if (EPI == 1) {
+                    const u32x2 sk = *reinterpret_cast<const u32x2*>(a.skip + row + ms * 32 + 8 * g + 4 * h);
+                    v[0] += from_bits<T>((unsigned short)(sk.x & 0xffff)); v[1] += from_bits<T>((unsigned short)(sk.x >> 16));
+                    v[2] += from_bits<T>((unsigned short)(sk.y & 0xffff)); v[3] += from_bits<T>((unsigned short)(sk.y >> 16));
+                }
+                pk[g][0] = to_bits<T>(v[0]) | ((unsigned)to_bits<T>(v[1]) << 16);
+                pk[g][1] = to_bits<T>(v[2]) | ((unsigned)to_bits<T>(v[3]) << 16);
+            }
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                // lanes 32-63 of group 2j <-> lanes 0-31 of group 2j + 1
+                const auto s0 = __builtin_amdgcn_permlane32_swap(pk[2 * j][0], pk[2 * j + 1][0], false, false);
+                const auto s1 = __builtin_amdgcn_permlane32_swap(pk[2 * j][1], pk[2 * j + 1][1], false, false);
+                const u32x4 o = { s0[0], s1[0], s0[1], s1[1] };
+                *reinterpret_cast<u32x4*>(outp + row + ms * 32 + 16 * j + 8 * h) = o;
+            }
+        }
+    }
+    WIDE_STAMP(5);
+}
+
+// ---------------------------------------------------------------------------------------------
+// tower128_kernel — the WHOLE 3x3 stack of a 128-filter net (stem + R residual blocks, nn.cpp:62-69) in one launch,
+// activations never leaving the CU.  conv4_mfma_kernel's loop already runs at 93 % of the MFMA issue rate, but per
+// layer it pays staging (7 000 clocks), an epilogue through HBM (12 000) and a launch for 19 800 clocks of MFMAs,
+// and moves 50 MB of activations per layer (0.9 GB per 10x128 forward at batch 1024, 51 MB algorithmic).  In
+// conv4's tiling a wave owns a whole board and all 128 channels, so nothing but the weights is shared between waves:
+// the layer boundary is wave-local — ReLU (+ the residual stream, kept as packed T in 64 registers: exactly the
+// operand the per-layer path re-reads from HBM), round, write the board's next input image in place (the wave's own
+// LDS operations are ordered; its MFMAs have all read the old image by then) — and the weight ring simply runs on
+// through all (1 + 2R) x 36 chunks.  Same reduction order and epilogue arithmetic as the per-layer kernels: same bits.
+struct Tower128Args {
+    const unsigned short* in;     // T [B][64][128]: the planes, converted and zero-padded (planes_to_act_kernel)
+    const unsigned short* w;      // (1 + 2R) layers x 36 chunks of 8 KB, pack_layer_wide128 order (Co = Ci = 128)
+    const float* shift;           // (1 + 2R) x 128 folded BatchNorm shifts
+    unsigned short* out;          // T [B][64][128]: the residual stream after the last block
+    int B, R;
+};
+
+template <typename T>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void tower128_kernel(Tower128Args a)
+{
+    constexpr int RDN = 4;
+    constexpr int LDS_IMG = RDN * CHUNKB;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    using V = typename Elem<T>::vec8;
+    const int tid = threadIdx.x, lane = tid & 63, h = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    constexpr int Ci = 128;
+    constexpr int stride = Ci * 2 + 16;
+    constexpr int board_bytes = NPIX * stride;
+    const int b0 = blockIdx.x * 4;
+    constexpr int NCH = 36;
+    const int NL = 1 + 2 * a.R, NCHT = NL * NCH;
+    const char* stream = reinterpret_cast<const char*>(a.w);
+    char* img = smem + LDS_IMG;
+
+#pragma unroll
+    for (int i = 0; i < RDN - 1; ++i) ring_issue<RDN>(stream, NCHT, i, wave, lane);
+    {
+        const u32x4 z = { 0, 0, 0, 0 };
+        constexpr int per_px = stride / 16;
+        for (int i = tid; i < 4 * NPIX; i += 256) {
+            const int pp = i % NPIX, yy = pp / PITCH, xx = pp % PITCH;
+            if (yy >= 1 && yy <= 8 && xx >= 1 && xx <= 8) continue;
+            char* d = img + (i / NPIX) * board_bytes + pp * stride;
+            for (int k = 0; k < per_px; ++k) *reinterpret_cast<u32x4*>(d + k * 16) = z;
+        }
+    }
+    {
+        u32x4 v[16];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) {
+            const int i = tid + u * 256;
+            const int bb = i >> 10, p = (i >> 4) & 63, c = i & 15;
+            v[u] = u32x4{ 0, 0, 0, 0 };
+            if (b0 + bb < a.B) v[u] = *reinterpret_cast<const u32x4*>(a.in + ((size_t)(b0 + bb) * 64 + p) * Ci + c * 8);
+        }
+#pragma unroll
+        for (int u = 0; u < 16; ++u) {
+            const int i = tid + u * 256;
+            const int bb = i >> 10, p = (i >> 4) & 63, c = i & 15;
+            const int pix = ((p >> 3) + 1) * PITCH + (p & 7) + 1;
+            *reinterpret_cast<u32x4*>(img + bb * board_bytes + pix * stride + c * 16) = v[u];
+        }
+    }
+    const int lp = PIXMAP[lane & 31];
+    const int py = lp >> 3, px = lp & 7;
+    const unsigned b_base = LDS_IMG + wave * board_bytes + (py * PITCH + px) * stride + h * 16;
+    constexpr unsigned HALF = 4 * PITCH * stride;
+    // where this lane's outputs go in its board's image: centre of the 3x3 window, its 4-channel groups
+    char* const w_base = smem + LDS_IMG + wave * board_bytes + ((py + 1) * PITCH + px + 1) * stride + h * 8;
+    f32x16 acc[8];
+    auto load_shift = [&](int l) {
+#pragma unroll
+        for (int ms = 0; ms < 4; ++ms)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const float4 s = *reinterpret_cast<const float4*>(a.shift + l * 128 + ms * 32 + 8 * g + 4 * h);
+#pragma unroll
+                for (int hp = 0; hp < 2; ++hp) {
+                    acc[ms * 2 + hp][4 * g + 0] = s.x; acc[ms * 2 + hp][4 * g + 1] = s.y;
+                    acc[ms * 2 + hp][4 * g + 2] = s.z; acc[ms * 2 + hp][4 * g + 3] = s.w;
+                }
+            }
+    };
+    load_shift(0);
+    auto chunk_off = [](int n) -> unsigned {
+        const int q = n / 18, tap = (n % 18) >> 1, half = n & 1;
+        return (unsigned)(((tap / 3) * PITCH + (tap % 3)) * stride) + q * 128 + half * 64;
+    };
+    V A[2][8], Bq[2][4];
+    unsigned xr[8][4][2];                                   // the residual stream of this lane's outputs, packed T (nn.cpp:31's `x`)
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) xr[i][g][0] = xr[i][g][1] = 0;
+
+    asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(2 * (RDN - 2)) : "memory");
+    {
+        const unsigned a_off = lane * 16;
+#pragma unroll
+        for (int f = 0; f < 8; ++f) A[0][f] = *reinterpret_cast<const V*>(smem + a_off + f * 1024);
+    }
+    for (int l = 0; l < NL; ++l) {
+#pragma unroll
+        for (int k = 0; k < 2; ++k)
+#pragma unroll
+            for (int hp = 0; hp < 2; ++hp) Bq[0][k * 2 + hp] = *reinterpret_cast<const V*>(smem + b_base + hp * HALF + chunk_off(0) + k * 32);
+#pragma unroll
+        for (int n = 0; n < NCH; ++n) {
+            const int cur = n & 1, nxt = cur ^ 1;
+            const int g = l * NCH + n;
+            asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(2 * (RDN - 3)) : "memory");
+            __builtin_amdgcn_sched_barrier(0);
+            ring_issue<RDN>(stream, NCHT, g + RDN - 1, wave, lane);
+            const unsigned a_off = (unsigned)(((n + 1) % RDN) * CHUNKB) + lane * 16;      // 36 chunks per layer: slot = n % 4
+#pragma unroll
+            for (int f = 0; f < 8; ++f) A[nxt][f] = *reinterpret_cast<const V*>(smem + a_off + f * 1024);
+            if (n + 1 < NCH) {
+#pragma unroll
+                for (int k = 0; k < 2; ++k)
+#pragma unroll
+                    for (int hp = 0; hp < 2; ++hp) Bq[nxt][k * 2 + hp] = *reinterpret_cast<const V*>(smem + b_base + hp * HALF + chunk_off(n + 1) + k * 32);
+            }
+#pragma unroll
+            for (int k = 0; k < 2; ++k)
+#pragma unroll
+                for (int ms = 0; ms < 4; ++ms)
+#pragma unroll
+                    for (int hp = 0; hp < 2; ++hp) acc[ms * 2 + hp] = Elem<T>::mfma(A[cur][k * 4 + ms], Bq[cur][k * 2 + hp], acc[ms * 2 + hp]);
+#pragma unroll
+            for (int i = 0; i < 12; ++i) {
+                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            }
+            __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+        }
+        // ---- layer boundary (this wave's board only).  l = 0: stem (nn.cpp:63-65); odd l: a block's first conv
+        // (nn.cpp:30); even l > 0: its second conv, ReLU before the add, none after (nn.cpp:31-33)
+        const bool add_skip = l > 0 && (l & 1) == 0, keep = (l & 1) == 0, last = l + 1 == NL;
+#pragma unroll
+        for (int hp = 0; hp < 2; ++hp)
+#pragma unroll
+            for (int ms = 0; ms < 4; ++ms)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    float v[4];
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) v[i] = relu_keep_nan(acc[ms * 2 + hp][4 * g + i]);
+                    if (add_skip) {
+                        const unsigned s0 = xr[ms * 2 + hp][g][0], s1 = xr[ms * 2 + hp][g][1];
+                        v[0] += from_bits<T>((unsigned short)(s0 & 0xffff)); v[1] += from_bits<T>((unsigned short)(s0 >> 16));
+                        v[2] += from_bits<T>((unsigned short)(s1 & 0xffff)); v[3] += from_bits<T>((unsigned short)(s1 >> 16));
+                    }
+                    const unsigned p0 = to_bits<T>(v[0]) | ((unsigned)to_bits<T>(v[1]) << 16);
+                    const unsigned p1 = to_bits<T>(v[2]) | ((unsigned)to_bits<T>(v[3]) << 16);
+                    if (keep) { xr[ms * 2 + hp][g][0] = p0; xr[ms * 2 + hp][g][1] = p1; }
+                    if (!last) *reinterpret_cast<u32x2*>(w_base + hp * HALF + (ms * 32 + 8 * g) * 2) = u32x2{ p0, p1 };
+                }
+        if (!last) load_shift(l + 1);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // drain the ring (tail re-fetches) before exit
+
+    // ---- the residual stream after the last block -> HBM (16-byte stores, as conv4_mfma_kernel's epilogue)
+    const int b = b0 + wave;
+    if (b >= a.B) return;
+#pragma unroll
+    for (int hp = 0; hp < 2; ++hp) {
+        const int pix = (4 * hp + py) * 8 + px;
+        const size_t row = ((size_t)b * 64 + pix) * 128;
+#pragma unroll
+        for (int ms = 0; ms < 4; ++ms)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const auto s0 = __builtin_amdgcn_permlane32_swap(xr[ms * 2 + hp][2 * j][0], xr[ms * 2 + hp][2 * j + 1][0], false, false);
+                const auto s1 = __builtin_amdgcn_permlane32_swap(xr[ms * 2 + hp][2 * j][1], xr[ms * 2 + hp][2 * j + 1][1], false, false);
+                const u32x4 o = { s0[0], s1[0], s0[1], s1[1] };
+                *reinterpret_cast<u32x4*>(a.out + row + ms * 32 + 16 * j + 8 * h) = o;
+            }
+    }
+}
+
 // valueconv + vbatchnorm + relu (nn.cpp:83-85) on T activations: one thread per (board, pixel)
 template <typename T>
 __global__ __launch_bounds__(256) void value_conv_kernel(const unsigned short* __restrict__ x, const float* __restrict__ vw,
@@ -578,6 +939,22 @@ template <typename T, int TAPS, int EPI, int CPT, int RDN, int NP = 1> static hi
     return hipGetLastError();
 }
 
+template <typename T, int EPI, int NP> static hipError_t launch_conv4(const ConvArgs& a, hipStream_t s)
+{
+    const int lds = 4 * CHUNKB + 4 * NPIX * (128 * 2 + 16);          // 163 328 B: one workgroup per CU
+    static std::atomic<bool> attr_done{ false };
+    if (!attr_done.load(std::memory_order_acquire)) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv4_mfma_kernel<T, EPI, NP>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) return e;
+        attr_done.store(true, std::memory_order_release);
+    }
+    ConvArgs b = a;
+    b.w = a.w4;
+    hipLaunchKernelGGL((conv4_mfma_kernel<T, EPI, NP>), dim3((a.B + 3) / 4, a.Co / 128), dim3(256), lds, s, b);
+    return hipGetLastError();
+}
+
 template <typename T, int TAPS, int EPI, int CPT> static hipError_t launch_conv_cpt(const ConvArgs& a, hipStream_t s)
 {
     // 3x3 layers with more workgroups than CUs: the 2-slot-ring variants, two workgroups per CU (128 input
@@ -585,7 +962,12 @@ template <typename T, int TAPS, int EPI, int CPT> static hipError_t launch_conv_
     // 10x128 at batch 1024: 726 -> 600 us per forward with two; with one workgroup per CU anyway the short ring
     // only costs (219 -> 251 us at batch 256), so this is decided per launch.
     const long wgs = (long)((a.B + 1) / 2) * (a.Co / 64);
-    static const int force = getenv("KAMI_WIDE_VARIANT") ? atoi(getenv("KAMI_WIDE_VARIANT")) : 0;   // experiments: 1, 2, 3 workgroups per CU
+    static const int force = getenv("KAMI_WIDE_VARIANT") ? atoi(getenv("KAMI_WIDE_VARIANT")) : 0;   // experiments: 1, 2, 3 workgroups per CU; 4 = four boards per workgroup
+    // four boards x 128 output channels per workgroup (conv4_mfma_kernel) once that still gives every CU a workgroup
+    if constexpr (TAPS == 9 && EPI != 2 && (CPT == 2 || CPT == 4)) {
+        const long wg4 = (long)((a.B + 3) / 4) * (a.Co / 128);
+        if (a.w4 && a.Co % 128 == 0 && (force == 4 || (!force && wg4 >= 256))) return launch_conv4<T, EPI, CPT / 2>(a, s);
+    }
     // measured (tools/wide_variants.py): 128 channels: three per CU is ahead from 512 workgroups on (+2 %, +14 % at
     // 2048); 256 channels: two and three are within 2 % of each other either way
     if constexpr (TAPS == 9 && CPT == 2) {
@@ -622,20 +1004,40 @@ template <typename T> static hipError_t run(const LayersArgs& L, hipStream_t s)
     hipError_t e;
     size_t li = 0;
     auto layer = [&](int idx) { return L.w + L.w_off[idx]; };
+    auto layer4 = [&](int idx) -> const unsigned short* { return (L.w4 && L.w4_off[idx] != (size_t)-1) ? L.w4 + L.w4_off[idx] : nullptr; };
     auto shift = [&](int idx) { return L.shift + L.shift_off[idx]; };
     ConvArgs a;
     a.B = L.B;
+    // 128 planes (padded) and 128 filters: the whole 3x3 stack in one launch, activations on chip (tower128_kernel).
+    // One workgroup per four boards: worth it once that keeps a good part of the CUs busy.
+    static const int force = getenv("KAMI_WIDE_VARIANT") ? atoi(getenv("KAMI_WIDE_VARIANT")) : 0;
+    const bool fused = L.FP == 128 && L.CP == 128 && L.w4 && layer4(0) && (force == 5 || (!force && L.B >= 384));
+    if (fused) {
+        static std::atomic<bool> attr_done{ false };
+        if (!attr_done.load(std::memory_order_acquire)) {
+            if ((e = hipFuncSetAttribute(reinterpret_cast<const void*>(&tower128_kernel<T>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)) != hipSuccess) return e;
+            attr_done.store(true, std::memory_order_release);
+        }
+        Tower128Args t8;
+        t8.in = L.act_in; t8.w = layer4(0); t8.shift = shift(0); t8.out = x; t8.B = L.B; t8.R = L.R;
+        hipLaunchKernelGGL((tower128_kernel<T>), dim3((L.B + 3) / 4), dim3(256), 4 * CHUNKB + 4 * NPIX * (128 * 2 + 16), s, t8);
+        if ((e = hipGetLastError()) != hipSuccess) return e;
+        li = 1 + 2 * (size_t)L.R;
+    }
     // stem                                                                  nn.cpp:62-65
-    a.in = L.act_in; a.w = layer(li); a.shift = shift(li); a.skip = nullptr; a.out = x; a.Ci = L.FP; a.Co = L.CP; ++li;
+    if (!fused) {
+    a.in = L.act_in; a.w = layer(li); a.w4 = layer4(li); a.shift = shift(li); a.skip = nullptr; a.out = x; a.Ci = L.FP; a.Co = L.CP; ++li;
     if ((e = launch_conv<T, 9, 0>(a, s)) != hipSuccess) return e;
-    for (int r = 0; r < L.R; ++r) {                                       // nn.cpp:26-34
-        a.in = x; a.w = layer(li); a.shift = shift(li); a.skip = nullptr; a.out = t; a.Ci = L.CP; a.Co = L.CP; ++li;
+    }
+    for (int r = 0; r < (fused ? 0 : L.R); ++r) {                         // nn.cpp:26-34
+        a.in = x; a.w = layer(li); a.w4 = layer4(li); a.shift = shift(li); a.skip = nullptr; a.out = t; a.Ci = L.CP; a.Co = L.CP; ++li;
         if ((e = launch_conv<T, 9, 0>(a, s)) != hipSuccess) return e;
-        a.in = t; a.w = layer(li); a.shift = shift(li); a.skip = x; a.out = u; ++li;
+        a.in = t; a.w = layer(li); a.w4 = layer4(li); a.shift = shift(li); a.skip = x; a.out = u; ++li;
         if ((e = launch_conv<T, 9, 1>(a, s)) != hipSuccess) return e;
         unsigned short* tmp = x; x = u; u = tmp;
     }
     // policy head                                                           nn.cpp:72-79
+    a.w4 = nullptr;
     a.in = x; a.w = layer(li); a.shift = shift(li); a.skip = nullptr; a.out = L.pmid; a.Ci = L.CP; a.Co = KH_POLICY_MID; ++li;
     if ((e = launch_conv<T, 1, 0>(a, s)) != hipSuccess) return e;
     a.in = L.pmid; a.w = layer(li); a.shift = shift(li); a.out = L.logits; a.Ci = KH_POLICY_MID; a.Co = 128; ++li;

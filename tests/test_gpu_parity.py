@@ -204,11 +204,13 @@ def test_forward_wide_nets_vs_oracle(dtype, F, C, R, B):
 
 
 @pytest.mark.parametrize("dtype", ["bf16", "f16"])
-@pytest.mark.parametrize("C,B,step", [(128, 513, 100), (128, 1024, 100), (256, 200, 50), (256, 131, 50)])
+@pytest.mark.parametrize("C,B,step", [(128, 513, 100), (128, 1024, 100), (128, 1021, 255), (256, 200, 50), (256, 131, 50), (256, 515, 103)])
 def test_wide_two_workgroups_per_cu_variant_matches(dtype, C, B, step):
-    """Wide nets: with more workgroups than CUs the 3x3 layers run the 2-slot-ring variant, two workgroups
-    per CU (256 channels: as two passes of 128).  It is the same arithmetic in the same order: the same
-    boards evaluated `step` at a time (4-slot variant, one workgroup per CU) must give the same bits."""
+    """Wide nets: the launcher picks the 3x3 layer kernel per call — one workgroup per CU with a 4-slot ring (small
+    batches), two or three per CU with a 2-slot ring and passes of 128 / 64 input channels, and from 256 workgroups of
+    FOUR boards x 128 output channels on conv4_mfma_kernel (128 channels: batch >= 1021; 256 channels: batch >= 509).
+    All of them walk the reduction in the same order with the same fp32 epilogue: the same boards evaluated `step`
+    at a time (another variant) must give the same bits, ragged last groups included."""
     F, R = 119, 2
     nn = NN(8, 8, F, 4672, filters=C, residuals=R, dtype=dtype)
     nn.load_weights(W.random_weights(F, C, R, seed=77, peaky=10.0), 1)

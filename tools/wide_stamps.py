@@ -8,7 +8,7 @@ if os.environ.get("KAMI_AB_LIB"):
     L.LIB_PATH = os.path.abspath(os.environ["KAMI_AB_LIB"])
 lib = L.load()
 raw = C.CDLL(L.LIB_PATH)
-for Cc, R, B, dt in ((128, 10, 1024, "bf16"), (256, 20, 256, "f16")):
+for Cc, R, B, dt in ((128, 10, 1024, "bf16"), (256, 20, 512, "f16")):
     F = 119
     nn = NN(8, 8, F, 4672, filters=Cc, residuals=R, dtype=dt)
     nn.load_weights(W.random_weights(F, Cc, R, seed=1), 1)
@@ -17,7 +17,8 @@ for Cc, R, B, dt in ((128, 10, 1024, "bf16"), (256, 20, 256, "f16")):
     lib.kh_dev_alloc(nn.handle, x.nbytes, C.byref(d_in)); lib.kh_dev_alloc(nn.handle, B*4672*4, C.byref(d_p)); lib.kh_dev_alloc(nn.handle, B*256*4, C.byref(d_v))
     lib.kh_memcpy_h2d(nn.handle, d_in, x.ctypes.data_as(C.c_void_p), x.nbytes)
     ms = C.c_float(); assert lib.kh_time_infer_device(nn.handle, d_in, B, d_p, d_v, 50, C.byref(ms)) == 0
-    nwg = (B // 2) * (Cc // 64)
+    four = os.environ.get("KAMI_WIDE_VARIANT") == "4"
+    nwg = ((B + 3) // 4) * (Cc // 128) if four else (B // 2) * (Cc // 64)
     st = np.zeros((2048, 8), np.uint64)
     assert raw.kh_debug_wide_stamps(st.ctypes.data_as(C.c_void_p), 2048 * 8) == 0
     st = st[:min(nwg, 2048)].astype(np.int64)
