@@ -201,6 +201,11 @@ void pack_layer(std::vector<uint16_t>& out, int dtype, const float* w, const flo
 void pack_layer_generic(std::vector<uint16_t>& out, int dtype, const float* w, const float* scale,
                         int Co, int Ci, int taps, int CoP, int CiP)
 {
+    // (runs at every weight install, the trainer's included: sized once, written by index)
+    const size_t base = out.size();
+    out.resize(base + (size_t)CoP * CiP * taps);
+    uint16_t* o = out.data() + base;
+    const bool bf = dtype == KH_BF16;
     for (int cb = 0; cb < CoP / 64; ++cb)
         for (int slice = 0; slice < CiP / 64; ++slice)
             for (int tap = 0; tap < taps; ++tap)
@@ -208,11 +213,12 @@ void pack_layer_generic(std::vector<uint16_t>& out, int dtype, const float* w, c
                     for (int ms = 0; ms < 2; ++ms)
                         for (int l = 0; l < 64; ++l) {
                             const int r = l & 31, h = l >> 5, ks = slice * 4 + kk;
+                            const int co = cb * 64 + ms * 32 + r, ci0 = ks * 16 + 8 * h;
+                            const float sc = scale ? (co < Co ? scale[co] : 0.0f) : 1.0f;
+                            const float* src = w + ((size_t)co * Ci + ci0) * taps + tap;
                             for (int j = 0; j < 8; ++j) {
-                                const int co = cb * 64 + ms * 32 + r, ci = ks * 16 + 8 * h + j;
-                                float v = 0.0f;
-                                if (co < Co && ci < Ci) v = w[((size_t)co * Ci + ci) * taps + tap] * (scale ? scale[co] : 1.0f);
-                                out.push_back(dtype == KH_BF16 ? f2bf16(v) : f2f16(v));
+                                const float v = (co < Co && ci0 + j < Ci) ? src[(size_t)j * taps] * sc : 0.0f;
+                                *o++ = bf ? f2bf16(v) : f2f16(v);
                             }
                         }
 }
@@ -223,6 +229,10 @@ void pack_layer_generic(std::vector<uint16_t>& out, int dtype, const float* w, c
 void pack_layer_wide128(std::vector<uint16_t>& out, int dtype, const float* w, const float* scale,
                         int Co, int Ci, int taps, int CoP, int CiP)
 {
+    const size_t base = out.size();
+    out.resize(base + (size_t)CoP * CiP * taps);
+    uint16_t* o = out.data() + base;
+    const bool bf = dtype == KH_BF16;
     for (int cb = 0; cb < CoP / 128; ++cb)
         for (int slice = 0; slice < CiP / 64; ++slice)
             for (int tap = 0; tap < taps; ++tap)
@@ -230,22 +240,24 @@ void pack_layer_wide128(std::vector<uint16_t>& out, int dtype, const float* w, c
                     for (int ms = 0; ms < 4; ++ms)
                         for (int l = 0; l < 64; ++l) {
                             const int r = l & 31, h = l >> 5, ks = slice * 4 + kk;
+                            const int co = cb * 128 + ms * 32 + r, ci0 = ks * 16 + 8 * h;
+                            const float sc = scale ? (co < Co ? scale[co] : 0.0f) : 1.0f;
+                            const float* src = w + ((size_t)co * Ci + ci0) * taps + tap;
                             for (int j = 0; j < 8; ++j) {
-                                const int co = cb * 128 + ms * 32 + r, ci = ks * 16 + 8 * h + j;
-                                float v = 0.0f;
-                                if (co < Co && ci < Ci) v = w[((size_t)co * Ci + ci) * taps + tap] * (scale ? scale[co] : 1.0f);
-                                out.push_back(dtype == KH_BF16 ? f2bf16(v) : f2f16(v));
+                                const float v = (co < Co && ci0 + j < Ci) ? src[(size_t)j * taps] * sc : 0.0f;
+                                *o++ = bf ? f2bf16(v) : f2f16(v);
                             }
                         }
 }
 
-// fp32 fragments for conv_f32_kernel: [Co/64][tap][Ci/8][2][lane][4]; lane (r, h) holds
-// W[co = ms*32 + r][ci = 8j + 4h + 0..3]
+// fp32 fragments for conv_f32_kernel: [Co/64][Ci slices of <= 128][tap][slice/8][2][lane][4]; lane (r, h) holds
+// W[co = ms*32 + r][ci = 8j + 4h + 0..3]  (one slice up to 128 input channels: the image of a slice is what fits LDS)
 void pack_layer_f32(std::vector<float>& out, const float* w, const float* scale, int Co, int Ci, int taps, int CoP, int CiP)
 {
     for (int cb = 0; cb < CoP / 64; ++cb)
+      for (int c_lo = 0; c_lo < CiP; c_lo += 128)
         for (int tap = 0; tap < taps; ++tap)
-            for (int j = 0; j < CiP / 8; ++j)
+            for (int j = c_lo / 8; j < (c_lo + 128 < CiP ? c_lo + 128 : CiP) / 8; ++j)
                 for (int ms = 0; ms < 2; ++ms)
                     for (int l = 0; l < 64; ++l) {
                         const int r = l & 31, h = l >> 5;
@@ -262,7 +274,7 @@ int build_layers(Weights& W, const HostNet& n, int dtype, int F, int C, int R)
     // bf16/f16: input channels in multiples of 64 (an 8 KB weight chunk = 4 k-steps of one tap)
     const int FP = f32 ? (F + 7) / 8 * 8 : (F + 63) / 64 * 64, CP = (C + 63) / 64 * 64;
     // LDS image of two boards: 2 x 120 x (Ci * elem + 16) bytes must fit 160 KB
-    if (f32 ? (CP > 128 || FP > 128) : (CP > 256 || FP > 256)) return KH_OK;      // not covered: ly_ok stays false
+    if (CP > 256 || FP > 256) return KH_OK;      // not covered: ly_ok stays false
     std::vector<uint16_t> w, w4;
     std::vector<float> wf;
     std::vector<float> shift;
@@ -1236,6 +1248,8 @@ int kh_train(kh_engine* e, const float* inputs, const float* obs_p, const float*
         ~GraphGuard() { if (x) (void)hipGraphExecDestroy(x); if (g) (void)hipGraphDestroy(g); }
     } graph;
     bool graph_tried = false;
+    HIPCHK(kh::conv_f32_raw_prepare());          // function attributes are not stream work: set them before any capture
+    static const bool trace = getenv("KAMI_TRAIN_TRACE") != nullptr;
     for (int epoch = 0; epoch < cfg->epochs; ++epoch) {
         std::shuffle(picker.begin(), picker.end(), rng);
         float avgloss = 0.0f;
@@ -1252,6 +1266,8 @@ int kh_train(kh_engine* e, const float* inputs, const float* obs_p, const float*
             HIPCHK(hipMemcpyAsync(dx.p, next_input, n_in * 4, hipMemcpyHostToDevice, st));
             HIPCHK(hipMemcpyAsync(dp.p, next_policy, n_p * 4, hipMemcpyHostToDevice, st));
             HIPCHK(hipMemcpyAsync(dv.p, next_value, (size_t)B * 4, hipMemcpyHostToDevice, st));
+            static const bool no_graph = getenv("KAMI_TRAIN_NOGRAPH") != nullptr;
+            if (!graph_tried && no_graph) graph_tried = true;
             if (!graph_tried) {
                 graph_tried = true;
                 if (hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal) == hipSuccess) {
@@ -1261,6 +1277,7 @@ int kh_train(kh_engine* e, const float* inputs, const float* obs_p, const float*
                         if (graph.x) { (void)hipGraphExecDestroy(graph.x); graph.x = nullptr; }
                         (void)hipGetLastError();
                     }
+                    if (trace) fprintf(stderr, "[kami train] step recorded as a graph: %s\n", graph.x ? "yes" : "NO (plain launches)");
                 }
             }
             if (graph.x) HIPCHK(hipGraphLaunch(graph.x, st));

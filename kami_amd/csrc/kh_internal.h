@@ -84,6 +84,12 @@ struct LayersArgs {
     float vshift;
 };
 size_t layers_lds_bytes(int Ci);
+// exact-fp32 MFMA convolution (conv_f32_kernel) for the trainer: out [B][64][Co] = conv(in [B][64][Ci]) + bias (nullable),
+// or out += conv(in) when `accumulate`.  packed_w: fragments in conv_f32_kernel's order, Co rounded up to 64,
+// [Co/64][Ci slices of <= 128][taps][slice/8][2][64 lanes][4] (train.hip packs them on the device).  Ci % 8 == 0.
+hipError_t conv_f32_raw_prepare();
+hipError_t launch_conv_f32_raw(const float* in, const float* packed_w, const float* bias, float* out, int B, int Ci, int Co, int taps,
+                               bool accumulate, hipStream_t s);
 hipError_t launch_layers(int dtype, const LayersArgs& L, hipStream_t s);
 
 // ---- train.hip ------------------------------------------------------------------------------

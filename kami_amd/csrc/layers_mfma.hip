@@ -15,6 +15,7 @@
 // B fragments from LDS, A fragments (pre-packed weights) through a 4-slot LDS ring fed by LDS-DMA.
 #include "kh_internal.h"
 
+#include <algorithm>
 #include <atomic>
 #include <cstdlib>
 
@@ -734,20 +735,24 @@ using f32x4v = __attribute__((ext_vector_type(4))) float;
 
 struct ConvArgsF32 {
     const float* in;      // [B][64][Ci]
-    const float* w;       // packed [Co/64][taps][Ci/8][2][64 lanes][4]
-    const float* shift;   // [Co]
+    const float* w;       // packed [Co/64][Ci slices of <= 128][taps][slice/8][2][64 lanes][4]  (one slice when Ci <= 128)
+    const float* shift;   // [Co] initial value of the accumulators (folded BatchNorm shift / bias), nullptr = 0
     const float* skip;    // [B][64][Co] or nullptr
-    float* out;           // [B][64][Co] (EPI 0/1) or [B][4672] (EPI 2)
-    int B, Ci, Co;        // Ci % 8 == 0, Co % 64 == 0
+    float* out;           // [B][64][Co] (EPI 0/1/3/4) or [B][4672] (EPI 2)
+    int B, Ci, Co;        // Ci % 8 == 0; the kernel computes Co rounded up to 64 and stores channels < Co
 };
 
+// EPI: 0 = ReLU; 1 = ReLU, + skip (nn.cpp:31); 2 = raw fp32 logits, planes < 73 (nn.cpp:75-79);
+//      3 = raw (training: the convolution + bias, BatchNorm follows in its own kernels); 4 = raw, added to what
+//      `out` already holds (training: a data gradient that joins another one)
 template <int TAPS, int EPI>
 __global__ __launch_bounds__(256) void conv_f32_kernel(ConvArgsF32 a)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 5;
-    const int Ci = a.Ci, Co = a.Co, KJ = Ci / 8;
-    const int stride = Ci * 4 + 16;                       // (Ci/4 + 1) 16-byte slots: odd -> conflict-free
+    const int Ci = a.Ci, Co = a.Co;
+    const int CS = Ci < 128 ? Ci : 128;                   // channels of one staged slice (Ci > 128: several passes)
+    const int stride = CS * 4 + 16;                       // (CS/4 + 1) 16-byte slots: odd -> conflict-free
     const int npx = (TAPS == 9) ? NPIX : 64;
     const int board_bytes = npx * stride;
     const int b0 = blockIdx.x * 2, cb = blockIdx.y;
@@ -761,17 +766,6 @@ __global__ __launch_bounds__(256) void conv_f32_kernel(ConvArgsF32 a)
             for (int k = 0; k < per_px; ++k) *reinterpret_cast<u32x4*>(d + k * 16) = z;
         }
     }
-    {
-        const int CH = Ci / 4;
-        for (int i = tid; i < 2 * 64 * CH; i += 256) {
-            const int bb = i / (64 * CH), p = (i / CH) & 63, c = i % CH;
-            u32x4 v = { 0, 0, 0, 0 };
-            if (b0 + bb < a.B) v = *reinterpret_cast<const u32x4*>(a.in + ((size_t)(b0 + bb) * 64 + p) * Ci + c * 4);
-            const int pix = (TAPS == 9) ? ((p >> 3) + 1) * PITCH + (p & 7) + 1 : p;
-            *reinterpret_cast<u32x4*>(smem + bb * board_bytes + pix * stride + c * 16) = v;
-        }
-    }
-    __syncthreads();
     const int wb = wave >> 1;
     const int lp = PIXMAP[lane & 31];
     const int py = 4 * (wave & 1) + (lp >> 3), px = lp & 7;
@@ -781,29 +775,49 @@ __global__ __launch_bounds__(256) void conv_f32_kernel(ConvArgsF32 a)
     for (int ms = 0; ms < 2; ++ms)
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
-            const float4 s = *reinterpret_cast<const float4*>(a.shift + cb * 64 + ms * 32 + 8 * g + 4 * h);
+            float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+            const int c0 = cb * 64 + ms * 32 + 8 * g + 4 * h;
+            if (a.shift) {
+                if (c0 + 3 < Co) s = *reinterpret_cast<const float4*>(a.shift + c0);
+                else { if (c0 < Co) s.x = a.shift[c0]; if (c0 + 1 < Co) s.y = a.shift[c0 + 1]; if (c0 + 2 < Co) s.z = a.shift[c0 + 2]; }
+            }
             acc[ms][4 * g + 0] = s.x; acc[ms][4 * g + 1] = s.y; acc[ms][4 * g + 2] = s.z; acc[ms][4 * g + 3] = s.w;
         }
-    const float* wp = a.w + ((size_t)cb * TAPS * KJ * 2) * 256 + lane * 4;     // 256 floats per fragment
-    const int TK = TAPS * KJ;
-    auto boff = [&](int kk) -> unsigned {
-        const int tap = kk / KJ, j = kk - tap * KJ;
-        return ((TAPS == 9) ? (unsigned)(((tap / 3) * PITCH + (tap % 3)) * stride) : 0u) + j * 32;
-    };
-    // operands two k-groups ahead in flight: one group is 8 MFMAs x 64 cycles, about one L2 round trip
-    auto ld = [&](int kk, f32x4v& x0, f32x4v& x1, f32x4v& xb) {
-        const int k = kk < TK ? kk : TK - 1;                       // past the end: harmless re-read
-        xb = *reinterpret_cast<const f32x4v*>(smem + b_base + boff(k));
-        x0 = *reinterpret_cast<const f32x4v*>(wp + (size_t)k * 512);
-        x1 = *reinterpret_cast<const f32x4v*>(wp + (size_t)k * 512 + 256);
-    };
-    // Three operand sets in fixed roles (no register rotation): k-group kk multiplies out of set kk % 3
-    // while the loads of k-group kk + 2 land in set (kk + 2) % 3.  The loads are pinned to the top of
-    // each step — left alone hipcc sinks them down to their first use two steps later and every step
-    // then waits for a full L2 round trip.
-    f32x4v wa[3], wb2[3], xb[3];
-    ld(0, wa[0], wb2[0], xb[0]);
-    ld(1, wa[1], wb2[1], xb[1]);
+    using f32x4v = __attribute__((ext_vector_type(4))) float;
+    for (int c_lo = 0; c_lo < Ci; c_lo += 128) {
+        const int cs = Ci - c_lo < 128 ? Ci - c_lo : 128, KJ = cs / 8, TK = TAPS * KJ;
+        if (c_lo) __syncthreads();                        // everybody is done reading the previous slice
+        {
+            const int CH = cs / 4;
+            for (int i = tid; i < 2 * 64 * CH; i += 256) {
+                const int bb = i / (64 * CH), p = (i / CH) & 63, c = i % CH;
+                u32x4 v = { 0, 0, 0, 0 };
+                if (b0 + bb < a.B) v = *reinterpret_cast<const u32x4*>(a.in + ((size_t)(b0 + bb) * 64 + p) * Ci + c_lo + c * 4);
+                const int pix = (TAPS == 9) ? ((p >> 3) + 1) * PITCH + (p & 7) + 1 : p;
+                *reinterpret_cast<u32x4*>(smem + bb * board_bytes + pix * stride + c * 16) = v;
+            }
+        }
+        __syncthreads();
+        // 256 floats per fragment; this block's slices are consecutive, each TAPS * (slice / 8) * 2 fragments
+        const float* wp = a.w + ((size_t)cb * TAPS * (Ci / 8) * 2 + (size_t)TAPS * (c_lo / 8) * 2) * 256 + lane * 4;
+        auto boff = [&](int kk) -> unsigned {
+            const int tap = kk / KJ, j = kk - tap * KJ;
+            return ((TAPS == 9) ? (unsigned)(((tap / 3) * PITCH + (tap % 3)) * stride) : 0u) + j * 32;
+        };
+        // operands two k-groups ahead in flight: one group is 8 MFMAs x 64 cycles, about one L2 round trip
+        auto ld = [&](int kk, f32x4v& x0, f32x4v& x1, f32x4v& xb) {
+            const int k = kk < TK ? kk : TK - 1;                       // past the end: harmless re-read
+            xb = *reinterpret_cast<const f32x4v*>(smem + b_base + boff(k));
+            x0 = *reinterpret_cast<const f32x4v*>(wp + (size_t)k * 512);
+            x1 = *reinterpret_cast<const f32x4v*>(wp + (size_t)k * 512 + 256);
+        };
+        // Three operand sets in fixed roles (no register rotation): k-group kk multiplies out of set kk % 3
+        // while the loads of k-group kk + 2 land in set (kk + 2) % 3.  The loads are pinned to the top of
+        // each step — left alone hipcc sinks them down to their first use two steps later and every step
+        // then waits for a full L2 round trip.
+        f32x4v wa[3], wb2[3], xb[3];
+        ld(0, wa[0], wb2[0], xb[0]);
+        ld(1, wa[1], wb2[1], xb[1]);
 #define KH_F32_STEP(kk, CUR, NXT2)                                                                     \
     {                                                                                                  \
         __builtin_amdgcn_sched_barrier(0);                                                             \
@@ -816,15 +830,16 @@ __global__ __launch_bounds__(256) void conv_f32_kernel(ConvArgsF32 a)
         __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);   /* the activation read */                 \
         __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);   /* then the MFMAs */                      \
     }
-    int kk = 0;
-    for (; kk + 2 < TK; kk += 3) {
-        KH_F32_STEP(kk, 0, 2)
-        KH_F32_STEP(kk + 1, 1, 0)
-        KH_F32_STEP(kk + 2, 2, 1)
-    }
-    if (kk < TK) { KH_F32_STEP(kk, 0, 2) ++kk; }
-    if (kk < TK) { KH_F32_STEP(kk, 1, 0) }
+        int kk = 0;
+        for (; kk + 2 < TK; kk += 3) {
+            KH_F32_STEP(kk, 0, 2)
+            KH_F32_STEP(kk + 1, 1, 0)
+            KH_F32_STEP(kk + 2, 2, 1)
+        }
+        if (kk < TK) { KH_F32_STEP(kk, 0, 2) ++kk; }
+        if (kk < TK) { KH_F32_STEP(kk, 1, 0) }
 #undef KH_F32_STEP
+    }
     const int b = b0 + wb;
     if (b >= a.B) return;
     const int p = py * 8 + px;
@@ -841,15 +856,150 @@ __global__ __launch_bounds__(256) void conv_f32_kernel(ConvArgsF32 a)
                     if (ch + i < KH_POLICY_PLANES) lo[ch + i] = v[i];
             } else {
                 const size_t o = ((size_t)b * 64 + p) * Co + ch;
+                if (EPI <= 1) {
 #pragma unroll
-                for (int i = 0; i < 4; ++i) v[i] = relu_keep_nan(v[i]);
-                if (EPI == 1) {
-                    const float4 s = *reinterpret_cast<const float4*>(a.skip + o);
-                    v[0] += s.x; v[1] += s.y; v[2] += s.z; v[3] += s.w;
+                    for (int i = 0; i < 4; ++i) v[i] = relu_keep_nan(v[i]);
                 }
-                *reinterpret_cast<float4*>(a.out + o) = make_float4(v[0], v[1], v[2], v[3]);
+                if (ch + 3 < Co && (Co & 3) == 0) {
+                    if (EPI == 1) {
+                        const float4 s = *reinterpret_cast<const float4*>(a.skip + o);
+                        v[0] += s.x; v[1] += s.y; v[2] += s.z; v[3] += s.w;
+                    }
+                    if (EPI == 4) {
+                        const float4 s = *reinterpret_cast<const float4*>(a.out + o);
+                        v[0] += s.x; v[1] += s.y; v[2] += s.z; v[3] += s.w;
+                    }
+                    *reinterpret_cast<float4*>(a.out + o) = make_float4(v[0], v[1], v[2], v[3]);
+                } else {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+                        if (ch + i < Co) {
+                            float r = v[i];
+                            if (EPI == 1) r += a.skip[o + i];
+                            if (EPI == 4) r += a.out[o + i];
+                            a.out[o + i] = r;
+                        }
+                }
             }
         }
+}
+
+// Small batches (the trainer's 8..64 boards): conv_f32_kernel's workgroup is 2 boards x 64 channels and a wave walks the
+// whole reduction alone — 16 workgroups at batch 32, each 144 k-groups x 8 MFMAs x 64 clocks long.  Here a workgroup is
+// ONE board x 32 channels and its four waves are (pixel half) x (HALF of the reduction): 8x the workgroups, a quarter of
+// the MFMAs per wave; the two halves of the reduction meet through LDS (fixed order: first half + second half).
+template <int TAPS, int EPI>
+__global__ __launch_bounds__(256) void conv_f32_small_kernel(ConvArgsF32 a)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    using f32x4v = __attribute__((ext_vector_type(4))) float;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 5;
+    const int Ci = a.Ci, Co = a.Co;
+    const int CS = Ci < 128 ? Ci : 128;
+    const int stride = CS * 4 + 16;
+    const int npx = (TAPS == 9) ? NPIX : 64;
+    const int board_bytes = npx * stride;
+    const int b = blockIdx.x, cb = blockIdx.y;           // cb: 32-channel block
+    const int ph = wave & 1, kh = wave >> 1;
+    if (TAPS == 9) {
+        const u32x4 z = { 0, 0, 0, 0 };
+        const int per_px = stride / 16;
+        for (int i = tid; i < NPIX; i += 256) {
+            const int yy = i / PITCH, xx = i % PITCH;
+            if (yy >= 1 && yy <= 8 && xx >= 1 && xx <= 8) continue;
+            char* d = smem + i * stride;
+            for (int k = 0; k < per_px; ++k) *reinterpret_cast<u32x4*>(d + k * 16) = z;
+        }
+    }
+    const int lp = PIXMAP[lane & 31];
+    const int py = 4 * ph + (lp >> 3), px = lp & 7;
+    const unsigned b_base = ((TAPS == 9) ? (py * PITCH + px) : (py * 8 + px)) * stride + h * 16;
+    f32x16 acc;
+#pragma unroll
+    for (int g = 0; g < 4; ++g)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int c = cb * 32 + 8 * g + 4 * h + i;
+            acc[4 * g + i] = (kh == 0 && a.shift && c < Co) ? a.shift[c] : 0.0f;
+        }
+    for (int c_lo = 0; c_lo < Ci; c_lo += 128) {
+        const int cs = Ci - c_lo < 128 ? Ci - c_lo : 128, KJ = cs / 8, TK = TAPS * KJ;
+        if (c_lo) __syncthreads();
+        {
+            const int CH = cs / 4;
+            for (int i = tid; i < 64 * CH; i += 256) {
+                const int p = i / CH, c = i % CH;
+                const u32x4 v = *reinterpret_cast<const u32x4*>(a.in + ((size_t)b * 64 + p) * Ci + c_lo + c * 4);
+                const int pix = (TAPS == 9) ? ((p >> 3) + 1) * PITCH + (p & 7) + 1 : p;
+                *reinterpret_cast<u32x4*>(smem + pix * stride + c * 16) = v;
+            }
+        }
+        __syncthreads();
+        // fragments of 64-channel block cb >> 1, row tile cb & 1 (the packing interleaves the two row tiles)
+        const float* wp = a.w + ((size_t)(cb >> 1) * TAPS * (Ci / 8) * 2 + (size_t)TAPS * (c_lo / 8) * 2) * 256 + (cb & 1) * 256 + lane * 4;
+        const int k_lo = kh ? (TK + 1) / 2 : 0, k_hi = kh ? TK : (TK + 1) / 2;
+        auto boff = [&](int kk) -> unsigned {
+            const int tap = kk / KJ, j = kk - tap * KJ;
+            return ((TAPS == 9) ? (unsigned)(((tap / 3) * PITCH + (tap % 3)) * stride) : 0u) + j * 32;
+        };
+        auto ld = [&](int kk, f32x4v& x0, f32x4v& xb) {
+            const int k = kk < k_hi ? kk : (k_hi > k_lo ? k_hi - 1 : 0);
+            xb = *reinterpret_cast<const f32x4v*>(smem + b_base + boff(k));
+            x0 = *reinterpret_cast<const f32x4v*>(wp + (size_t)k * 512);
+        };
+        f32x4v wa[3], xb[3];
+        ld(k_lo, wa[0], xb[0]);
+        ld(k_lo + 1, wa[1], xb[1]);
+#define KH_F32S_STEP(kk, CUR, NXT2)                                                                    \
+    {                                                                                                  \
+        __builtin_amdgcn_sched_barrier(0);                                                             \
+        ld((kk) + 2, wa[NXT2], xb[NXT2]);                                                              \
+        _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                  \
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wa[CUR][i], xb[CUR][i], acc, 0, 0, 0);          \
+        __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);                                             \
+        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                                             \
+        __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);                                             \
+    }
+        int kk = k_lo;
+        for (; kk + 2 < k_hi; kk += 3) {
+            KH_F32S_STEP(kk, 0, 2)
+            KH_F32S_STEP(kk + 1, 1, 0)
+            KH_F32S_STEP(kk + 2, 2, 1)
+        }
+        if (kk < k_hi) { KH_F32S_STEP(kk, 0, 2) ++kk; }
+        if (kk < k_hi) { KH_F32S_STEP(kk, 1, 0) }
+#undef KH_F32S_STEP
+    }
+    // second half of the reduction -> LDS -> first half's waves (the image is dead)
+    __syncthreads();
+    float* red = reinterpret_cast<float*>(smem) + (size_t)ph * 64 * 16;
+    if (kh == 1) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) red[i * 64 + lane] = acc[i];
+    }
+    __syncthreads();
+    if (kh == 1) return;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] += red[i * 64 + lane];
+    const int p = py * 8 + px;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        const int ch = cb * 32 + 8 * g + 4 * h;
+        float v[4] = { acc[4 * g], acc[4 * g + 1], acc[4 * g + 2], acc[4 * g + 3] };
+        const size_t o = ((size_t)b * 64 + p) * Co + ch;
+        if (EPI <= 1) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) v[i] = relu_keep_nan(v[i]);
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            if (ch + i < Co) {
+                float r = v[i];
+                if (EPI == 1) r += a.skip[o + i];
+                if (EPI == 4) r += a.out[o + i];
+                a.out[o + i] = r;
+            }
+    }
 }
 
 // fp32 planes [B][64][F] -> [B][64][FP] zero-padded (FP = F rounded up to 8)
@@ -876,7 +1026,7 @@ __global__ __launch_bounds__(256) void value_conv_f32_kernel(const float* __rest
 
 template <int TAPS, int EPI> static hipError_t launch_conv_f32(const ConvArgsF32& a, hipStream_t s)
 {
-    const int lds = 2 * ((TAPS == 9) ? NPIX : 64) * (a.Ci * 4 + 16);
+    const int lds = 2 * ((TAPS == 9) ? NPIX : 64) * ((a.Ci < 128 ? a.Ci : 128) * 4 + 16);
     static std::atomic<bool> attr_done{ false };      // engines are called from many host threads; setting it twice is harmless
     if (!attr_done.load(std::memory_order_acquire)) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_f32_kernel<TAPS, EPI>),
@@ -884,7 +1034,22 @@ template <int TAPS, int EPI> static hipError_t launch_conv_f32(const ConvArgsF32
         if (e != hipSuccess) return e;
         attr_done.store(true, std::memory_order_release);
     }
-    hipLaunchKernelGGL((conv_f32_kernel<TAPS, EPI>), dim3((a.B + 1) / 2, a.Co / 64), dim3(256), lds, s, a);
+    // few boards (the trainer): one board x 32 channels per workgroup, the reduction split over its waves
+    if constexpr (EPI == 3 || EPI == 4) {
+        if ((long)((a.B + 1) / 2) * ((a.Co + 63) / 64) < 128) {
+            static std::atomic<bool> attr2_done{ false };
+            if (!attr2_done.load(std::memory_order_acquire)) {
+                hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_f32_small_kernel<TAPS, EPI>),
+                                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+                if (e != hipSuccess) return e;
+                attr2_done.store(true, std::memory_order_release);
+            }
+            const int lds1 = std::max(lds / 2, 2 * 64 * 16 * 4);
+            hipLaunchKernelGGL((conv_f32_small_kernel<TAPS, EPI>), dim3(a.B, (a.Co + 31) / 32), dim3(256), lds1, s, a);
+            return hipGetLastError();
+        }
+    }
+    hipLaunchKernelGGL((conv_f32_kernel<TAPS, EPI>), dim3((a.B + 1) / 2, (a.Co + 63) / 64), dim3(256), lds, s, a);
     return hipGetLastError();
 }
 
@@ -1059,6 +1224,32 @@ extern "C" int kh_debug_wide_stamps(unsigned long long* out, int n)
 #endif
 
 size_t layers_lds_bytes(int Ci) { return (size_t)lay::LDS_IMG + (size_t)2 * lay::NPIX * (Ci * 2 + 16); }
+
+// sets the kernels' dynamic-LDS attribute outside any stream capture (kh_train records a step as a graph)
+hipError_t conv_f32_raw_prepare()
+{
+    const void* fns[] = {
+        reinterpret_cast<const void*>(&lay::conv_f32_kernel<9, 3>), reinterpret_cast<const void*>(&lay::conv_f32_kernel<9, 4>),
+        reinterpret_cast<const void*>(&lay::conv_f32_kernel<1, 3>), reinterpret_cast<const void*>(&lay::conv_f32_kernel<1, 4>),
+        reinterpret_cast<const void*>(&lay::conv_f32_small_kernel<9, 3>), reinterpret_cast<const void*>(&lay::conv_f32_small_kernel<9, 4>),
+        reinterpret_cast<const void*>(&lay::conv_f32_small_kernel<1, 3>), reinterpret_cast<const void*>(&lay::conv_f32_small_kernel<1, 4>),
+    };
+    for (const void* f : fns) {
+        const hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) return e;
+    }
+    return hipSuccess;
+}
+
+// the exact-fp32 MFMA convolution for the trainer (train.hip): out = conv(in) (+ bias), raw or added to `out`
+hipError_t launch_conv_f32_raw(const float* in, const float* packed_w, const float* bias, float* out, int B, int Ci, int Co, int taps,
+                               bool accumulate, hipStream_t s)
+{
+    lay::ConvArgsF32 a;
+    a.in = in; a.w = packed_w; a.shift = bias; a.skip = nullptr; a.out = out; a.B = B; a.Ci = Ci; a.Co = Co;
+    if (taps == 9) return accumulate ? lay::launch_conv_f32<9, 4>(a, s) : lay::launch_conv_f32<9, 3>(a, s);
+    return accumulate ? lay::launch_conv_f32<1, 4>(a, s) : lay::launch_conv_f32<1, 3>(a, s);
+}
 
 hipError_t launch_layers(int dtype, const LayersArgs& L, hipStream_t s)
 {

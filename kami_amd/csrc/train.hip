@@ -15,6 +15,8 @@
 // Activations are [B][64][C] fp32 channels-last like forward_simple.hip.
 #include "kh_internal.h"
 
+#include <algorithm>
+#include <cstdlib>
 #include <vector>
 
 namespace kh {
@@ -218,6 +220,147 @@ void launch_conv_wgrad(const float* dy, const float* x, float* dw, float* db, in
         const dim3 grid((Co + 7) / 8, (Ci + 7) / 8);
         if (T == 9) hipLaunchKernelGGL(conv_wgrad_split_kernel<9>, grid, dim3(256), 0, s, dy, x, dw, db, B, Ci, Co);
         else hipLaunchKernelGGL(conv_wgrad_split_kernel<1>, grid, dim3(256), 0, s, dy, x, dw, db, B, Ci, Co);
+    }
+}
+
+// ---- the three convolution GEMMs on the matrix cores, exact fp32 (v_mfma_f32_32x32x2_f32) ----------------------
+// forward and data gradient run layers_mfma.hip's conv_f32_kernel (launch_conv_f32_raw): the data gradient of a
+// convolution is a convolution of dy with the weights transposed (co <-> ci) and the taps mirrored, so both only
+// need the layer's weights as MFMA fragments — re-packed on the device from the canonical blob after every SGD
+// step (pack_f32_kernel).  The weight gradient is its own kernel below.
+//
+// dst[cb][slice][tap][j][ms][lane][i] = W(o = cb*64 + ms*32 + (lane & 31), k = 8j + 4(lane >> 5) + i, tap)
+//   forward: W(o, k, tap) = w[o][k][tap]                     (o = co, k = ci)
+//   dgrad  : W(o, k, tap) = w[k][o][T - 1 - tap]             (o = ci, k = co; taps mirrored)
+// every layer's fragments in one launch (the weights only change at the SGD update): blockIdx.y = job
+struct PackJob { const float* src; float* dst; int Co, Ci, T, dgrad; };
+constexpr int PACK_JOBS = 40;
+struct PackJobs { PackJob j[PACK_JOBS]; };
+__global__ __launch_bounds__(256) void pack_f32_jobs_kernel(PackJobs jobs)
+{
+    const PackJob& jb = jobs.j[blockIdx.y];
+    const float* __restrict__ w = jb.src;
+    float* __restrict__ dst = jb.dst;
+    const int Co = jb.Co, Ci = jb.Ci, T = jb.T, dgrad = jb.dgrad;
+    const int O = dgrad ? Ci : Co, K = dgrad ? Co : Ci;
+    const int KP = (K + 7) / 8 * 8, OB = (O + 63) / 64;
+    const long total = (long)OB * T * (KP / 8) * 2 * 256;
+    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+        long r = idx;
+        const int i = (int)(r & 3); r >>= 2;
+        const int lane = (int)(r & 63); r >>= 6;
+        const int ms = (int)(r & 1); r >>= 1;
+        const long per_cb = (long)T * (KP / 8);
+        const int cb = (int)(r / per_cb);
+        long q = r - (long)cb * per_cb;
+        int c_lo = 0;
+        for (;;) {
+            const int cs = KP - c_lo < 128 ? KP - c_lo : 128;
+            const long in_slice = (long)T * (cs / 8);
+            if (q < in_slice) {
+                const int tap = (int)(q / (cs / 8)), j = c_lo / 8 + (int)(q % (cs / 8));
+                const int o = cb * 64 + ms * 32 + (lane & 31), k = 8 * j + 4 * (lane >> 5) + i;
+                float v = 0.0f;
+                if (o < O && k < K) v = dgrad ? w[((size_t)k * Ci + o) * T + (T - 1 - tap)] : w[((size_t)o * Ci + k) * T + tap];
+                dst[idx] = v;
+                break;
+            }
+            q -= in_slice; c_lo += 128;
+        }
+    }
+}
+
+inline size_t packed_f32_floats(int O, int K, int T) { return (size_t)((O + 63) / 64) * T * ((K + 7) / 8) * 2 * 256; }
+
+// Weight gradient: dw[co][ci][tap] = sum over boards and pixels of dy[b][p][co] * x[b][p + off(tap)][ci] — per tap a
+// [Co x (B*64)] x [(B*64) x Ci] GEMM whose reduction runs over pixels: an MFMA consumes two pixels (K = 2), its A
+// operand dy[pixel][co] and its B operand x[shifted pixel][ci] are both read from LDS with the channel on the lane.
+// Workgroup = 64 co x 64 ci (wave = 32 x 32, all T taps: 9 accumulators) x a range of boards; the board ranges'
+// partial sums go to `part` and are added in range order by wgrad_reduce_kernel (deterministic).
+constexpr int WG_PITCH = 12, WG_NPIX = 10 * WG_PITCH, WG_S = 65;
+template <int T>
+__global__ __launch_bounds__(256) void conv_wgrad_mfma_kernel(const float* __restrict__ dy, const float* __restrict__ x, float* __restrict__ part,
+                                                              int B, int Ci, int Co, int xs /* channel stride of x */, int boards_per_split)
+{
+    using f32x16 = __attribute__((ext_vector_type(16))) float;
+    __shared__ float dy_s[64 * WG_S];
+    __shared__ float x_s[(T == 9 ? WG_NPIX : 64) * WG_S];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int co0 = blockIdx.x * 64, ci0 = blockIdx.y * 64, split = blockIdx.z;
+    const int cq = wave >> 1, iq = wave & 1, r = lane & 31, kk = lane >> 5;
+    if (T == 9)
+        for (int i = tid; i < WG_NPIX * WG_S; i += 256) x_s[i] = 0.0f;      // the halo stays zero
+    f32x16 acc[T];
+#pragma unroll
+    for (int t = 0; t < T; ++t)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[t][i] = 0.0f;
+    const int b_lo = split * boards_per_split, b_hi = b_lo + boards_per_split < B ? b_lo + boards_per_split : B;
+    for (int b = b_lo; b < b_hi; ++b) {
+        __syncthreads();
+        for (int i = tid; i < 64 * 64; i += 256) {
+            const int q = i >> 6, c = i & 63;
+            dy_s[q * WG_S + c] = co0 + c < Co ? dy[((long)b * 64 + q) * Co + co0 + c] : 0.0f;
+            const int pix = T == 9 ? ((q >> 3) + 1) * WG_PITCH + (q & 7) + 1 : q;
+            x_s[pix * WG_S + c] = ci0 + c < Ci ? x[((long)b * 64 + q) * xs + ci0 + c] : 0.0f;
+        }
+        __syncthreads();
+#pragma unroll 4
+        for (int p0 = 0; p0 < 64; p0 += 2) {
+            const int p = p0 + kk;                                           // this lane's pixel of the pair
+            const float av = dy_s[p * WG_S + cq * 32 + r];
+            const float* xq = x_s + (T == 9 ? ((p >> 3) * WG_PITCH + (p & 7)) : p) * WG_S + iq * 32 + r;   // tap (0,0) of the window
+#pragma unroll
+            for (int t = 0; t < T; ++t)
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, xq[(T == 9 ? (t / 3) * WG_PITCH + t % 3 : 0) * WG_S], acc[t], 0, 0, 0);
+        }
+    }
+    // C/D layout: column (lane & 31) = ci, row (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5) = co
+    float* dst = part + (size_t)split * Co * Ci * T;
+    const int ci = ci0 + iq * 32 + r;
+    if (ci < Ci) {
+#pragma unroll
+        for (int reg = 0; reg < 16; ++reg) {
+            const int co = co0 + cq * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * kk;
+            if (co < Co) {
+#pragma unroll
+                for (int t = 0; t < T; ++t) dst[((size_t)co * Ci + ci) * T + t] = acc[t][reg];
+            }
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ part, float* __restrict__ dw, long n, int splits)
+{
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        float s = part[i];
+        for (int k = 1; k < splits; ++k) s += part[(size_t)k * n + i];
+        dw[i] = s;
+    }
+}
+
+// db[co] = sum over boards and pixels of dy: one workgroup per channel, fixed order
+__global__ __launch_bounds__(256) void bias_grad_kernel(const float* __restrict__ dy, float* __restrict__ db, int N, int C)
+{
+    __shared__ float red[4];
+    const int c = blockIdx.x;
+    float s = 0.0f;
+    for (int i = threadIdx.x; i < N; i += 256) s += dy[(long)i * C + c];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) db[c] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+
+// [B][64][F] -> [B][64][FP] zero-padded
+__global__ __launch_bounds__(256) void pad_channels_kernel(const float* __restrict__ in, float* __restrict__ out, long npix, int F, int FP)
+{
+    const long total = npix * FP;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const long p = i / FP;
+        const int c = (int)(i % FP);
+        out[i] = c < F ? in[p * F + c] : 0.0f;
     }
 }
 
@@ -431,12 +574,40 @@ static TrainNet layout(int F, int C, int R)
 // One SGD step on device buffers (StepBuffers: params = blob updated in place, grads = blob-shaped,
 // work = train_workspace_floats() floats of activations, conv outputs, statistics and gradients).
 
+// board ranges of the weight gradient: enough workgroups to fill the chip, at least one board each
+static int train_wgrad_splits(int B, int Ci, int Co)
+{
+    const int tiles = ((Co + 63) / 64) * ((Ci + 63) / 64);
+    int want = (256 + tiles - 1) / tiles;
+    if (want > B) want = B;
+    if (want < 1) want = 1;
+    const int per = (B + want - 1) / want;
+    return (B + per - 1) / per;
+}
+
+// floats of the weight gradient's partial-sum buffer: the largest layer's (ranges x Co x Ci x taps)
+static size_t train_wgrad_part_floats(int F, int C, int B)
+{
+    const int FP = (F + 7) / 8 * 8;
+    size_t m = (size_t)train_wgrad_splits(B, FP, C) * C * FP * 9;                                    // stem
+    m = std::max(m, (size_t)train_wgrad_splits(B, C, C) * C * C * 9);                               // tower
+    m = std::max(m, (size_t)train_wgrad_splits(B, C, KH_POLICY_MID) * KH_POLICY_MID * C);           // policyconv
+    return m;
+}
+
 size_t train_workspace_floats(int F, int C, int R, int B)
 {
     const size_t act = (size_t)B * 64 * (size_t)(C > KH_POLICY_MID ? C : KH_POLICY_MID);
     const int L = 1 + 2 * R;
     // per tower layer: output activation + conv output; heads: pconv y/act, logits, dlogits, value pieces; 3 gradient planes
-    return act * (2 * (size_t)L + 12) + (size_t)B * 64 * F + (size_t)B * KH_PSIZE * 2 + (size_t)(2 * L + 8) * 2 * 256 + 65536;
+    size_t n = act * (2 * (size_t)L + 12) + (size_t)B * 64 * F + (size_t)B * KH_PSIZE * 2 + (size_t)(2 * L + 8) * 2 * 256 + 65536;
+    // MFMA path: the stem input padded to a multiple of 8 planes, every tower / policy-conv layer's weights as forward
+    // and data-gradient fragments, the weight gradient's per-board-range partial sums
+    const int FP = (F + 7) / 8 * 8, CM = C > KH_POLICY_MID ? C : KH_POLICY_MID;
+    n += (size_t)B * 64 * FP;
+    n += packed_f32_floats(C, FP, 9) + (size_t)2 * R * 2 * packed_f32_floats(C, C, 9) + 2 * packed_f32_floats(CM, CM, 1);
+    n += train_wgrad_part_floats(F, C, B) + 65536;
+    return n;
 }
 
 hipError_t train_step(const TrainNet& n, const StepBuffers& sb, const float* x_in, const float* obsp, const float* obsv,
@@ -448,14 +619,77 @@ hipError_t train_step(const TrainNet& n, const StepBuffers& sb, const float* x_i
     float* wk = sb.work;
     auto take = [&](size_t nfl) { float* r = wk; wk += nfl; return r; };
     const size_t actC = (size_t)B * 64 * C;
-    struct Saved { const float* in; float* y; float* out; float* mean; float* invstd; };
+    struct Saved { const float* in; float* y; float* out; float* mean; float* invstd; int in_stride; const float* wf; const float* wd; };
     std::vector<Saved> sv;
     (void)hipMemsetAsync(G, 0, n.total * sizeof(float), s);
+    // matrix-core path (exact fp32 MFMA) for the layers that carry the work: channel counts in multiples of 8
+    // (KAMI_TRAIN_VALU=1 keeps every convolution on the order-exact VALU kernels above)
+    static const bool valu_only = getenv("KAMI_TRAIN_VALU") && atoi(getenv("KAMI_TRAIN_VALU")) != 0;
+    auto on_mfma = [&](const ConvBNOff& c) { return !valu_only && c.Co % 8 == 0 && c.Co >= 8 && (c.Ci % 8 == 0 || &c == &n.stem); };
+    const int FP = (n.F + 7) / 8 * 8;
+    const float* x_pad = x_in;
+    if (on_mfma(n.stem) && FP != n.F) {
+        float* xp = take((size_t)N * FP);
+        hipLaunchKernelGGL(pad_channels_kernel, dim3(nblocks((long)N * FP)), dim3(256), 0, s, x_in, xp, (long)N, n.F, FP);
+        x_pad = xp;
+    }
+    float* wpart = nullptr;
+    // every MFMA layer's weights as forward / data-gradient fragments, packed up front in as few launches as it takes
+    struct Packed { const float* wf = nullptr; const float* wd = nullptr; };
+    std::vector<const ConvBNOff*> mlayers;
+    mlayers.push_back(&n.stem);
+    for (auto& c : n.res) mlayers.push_back(&c);
+    mlayers.push_back(&n.pconv);
+    std::vector<Packed> packed(mlayers.size());
+    {
+        PackJobs jobs;
+        int nj = 0;
+        long biggest = 0;
+        auto flush = [&]() {
+            if (!nj) return;
+            int bx = (int)((biggest + 255) / 256);
+            if (bx > 256) bx = 256;
+            hipLaunchKernelGGL(pack_f32_jobs_kernel, dim3(bx, nj), dim3(256), 0, s, jobs);
+            nj = 0; biggest = 0;
+        };
+        auto add = [&](const float* src, float* dst, int Co, int Ci, int T, int dgrad, size_t count) {
+            jobs.j[nj++] = PackJob{ src, dst, Co, Ci, T, dgrad };
+            biggest = std::max(biggest, (long)count);
+            if (nj == PACK_JOBS) flush();
+        };
+        for (size_t i = 0; i < mlayers.size(); ++i) {
+            const ConvBNOff& c = *mlayers[i];
+            if (!on_mfma(c)) continue;
+            const int CiP = (c.Ci + 7) / 8 * 8;
+            float* wf = take(packed_f32_floats(c.Co, CiP, c.T));
+            add(P + c.w, wf, c.Co, c.Ci, c.T, 0, packed_f32_floats(c.Co, CiP, c.T));
+            packed[i].wf = wf;
+            if (&c != &n.stem) {                     // the stem's input needs no gradient
+                float* wd = take(packed_f32_floats(c.Ci, c.Co, c.T));
+                add(P + c.w, wd, c.Co, c.Ci, c.T, 1, packed_f32_floats(c.Ci, c.Co, c.T));
+                packed[i].wd = wd;
+            }
+        }
+        flush();
+    }
+    auto packed_of = [&](const ConvBNOff& c) -> const Packed& {
+        for (size_t i = 0; i < mlayers.size(); ++i)
+            if (mlayers[i] == &c) return packed[i];
+        static const Packed none;
+        return none;
+    };
 
     auto fwd = [&](const ConvBNOff& c, const float* in, const float* skip) {
         Saved v;
-        v.in = in;
+        v.in = in; v.in_stride = c.Ci; v.wf = v.wd = nullptr;
         v.y = take((size_t)N * c.Co); v.out = take((size_t)N * c.Co); v.mean = take(256); v.invstd = take(256);
+        if (on_mfma(c)) {
+            const int CiP = (c.Ci + 7) / 8 * 8;
+            if (&c == &n.stem) { v.in = x_pad; v.in_stride = CiP; }
+            const Packed& pk = packed_of(c);
+            v.wf = pk.wf; v.wd = pk.wd;
+            (void)launch_conv_f32_raw(v.in, v.wf, P + c.b, v.y, B, CiP, c.Co, c.T, false, s);
+        } else
         launch_conv_tiled<false>(P + c.w, P + c.b, in, v.y, B, c.Ci, c.Co, c.T, 0, s);
         hipLaunchKernelGGL(bn_stats_kernel, dim3(c.Co), dim3(256), 0, s, v.y, v.mean, v.invstd, P + c.rm, P + c.rv, N, c.Co);
         hipLaunchKernelGGL(bn_relu_fwd_kernel, dim3(nblocks((long)N * c.Co)), dim3(256), 0, s, v.y, v.mean, v.invstd, P + c.g, P + c.be, skip, v.out,
@@ -468,6 +702,18 @@ hipError_t train_step(const TrainNet& n, const StepBuffers& sb, const float* x_i
         hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(c.Co), dim3(256), 0, s, dout, v.y, v.mean, v.invstd, P + c.g, P + c.be, G + c.g, G + c.be, N, c.Co);
         hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(nblocks((long)N * c.Co)), dim3(256), 0, s, dout, v.y, v.mean, v.invstd, P + c.g, P + c.be,
                            G + c.g, G + c.be, dy_tmp, (long)N * c.Co, c.Co, N);
+        if (v.wf) {
+            const int splits = train_wgrad_splits(B, c.Ci, c.Co), per = (B + splits - 1) / splits;
+            const size_t nw = (size_t)c.Co * c.Ci * c.T;
+            const dim3 grid((c.Co + 63) / 64, (c.Ci + 63) / 64, splits);
+            float* part = splits > 1 ? wpart : G + c.w;
+            if (c.T == 9) hipLaunchKernelGGL(conv_wgrad_mfma_kernel<9>, grid, dim3(256), 0, s, dy_tmp, v.in, part, B, c.Ci, c.Co, v.in_stride, per);
+            else hipLaunchKernelGGL(conv_wgrad_mfma_kernel<1>, grid, dim3(256), 0, s, dy_tmp, v.in, part, B, c.Ci, c.Co, v.in_stride, per);
+            if (splits > 1) hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(nblocks((long)nw)), dim3(256), 0, s, part, G + c.w, (long)nw, splits);
+            hipLaunchKernelGGL(bias_grad_kernel, dim3(c.Co), dim3(256), 0, s, dy_tmp, G + c.b, N, c.Co);
+            if (din) (void)launch_conv_f32_raw(dy_tmp, v.wd, nullptr, din, B, c.Co, c.Ci, c.T, acc != 0, s);
+            return;
+        }
         launch_conv_wgrad(dy_tmp, v.in, G + c.w, G + c.b, B, c.Ci, c.Co, c.T, s);
         if (din)
             launch_conv_tiled<true>(P + c.w, nullptr, dy_tmp, din, B, c.Ci, c.Co, c.T, acc, s);
@@ -492,6 +738,7 @@ hipError_t train_step(const TrainNet& n, const StepBuffers& sb, const float* x_i
     hipLaunchKernelGGL(value_fwd_loss_kernel, dim3(B), dim3(256), 0, s, h, P + n.fcw, P + n.fcb, obsv, dpre, loss_rows + B, B);
 
     // ---- backward ----
+    wpart = take(train_wgrad_part_floats(n.F, C, B));
     float* dX = take(actC);             // gradient w.r.t. the tower output, then walked down the tower
     float* dT = take((size_t)N * (C > KH_POLICY_MID ? C : KH_POLICY_MID));
     float* dtmp = take((size_t)N * (C > KH_POLICY_MID ? C : KH_POLICY_MID));
