@@ -624,7 +624,7 @@ hipError_t train_step(const TrainNet& n, const StepBuffers& sb, const float* x_i
     (void)hipMemsetAsync(G, 0, n.total * sizeof(float), s);
     // matrix-core path (exact fp32 MFMA) for the layers that carry the work: channel counts in multiples of 8
     // (KAMI_TRAIN_VALU=1 keeps every convolution on the order-exact VALU kernels above)
-    static const bool valu_only = getenv("KAMI_TRAIN_VALU") && atoi(getenv("KAMI_TRAIN_VALU")) != 0;
+    const bool valu_only = getenv("KAMI_TRAIN_VALU") && atoi(getenv("KAMI_TRAIN_VALU")) != 0;   // read when a step is recorded
     auto on_mfma = [&](const ConvBNOff& c) { return !valu_only && c.Co % 8 == 0 && c.Co >= 8 && (c.Ci % 8 == 0 || &c == &n.stem); };
     const int FP = (n.F + 7) / 8 * 8;
     const float* x_pad = x_in;

@@ -97,8 +97,13 @@ def gen_train(tmp):
     nn.cpp:296-312), so with several batches per epoch every step of the epoch would train on the last
     batch built; on its CUDA path `.to(device)` copies and the batches are distinct.  kh_train follows the
     CUDA path, and single-batch epochs are where the two coincide."""
-    for name, F, C, R, n, tbatch, epochs, mlr, seed in (("train_f30_c16_r1", 30, 16, 1, 8, 8, 4, 5, 11),
-                                                        ("train_f30_c8_r2", 30, 8, 2, 6, 6, 5, 20, 12)):
+    cases = (("train_f30_c16_r1", 30, 16, 1, 8, 8, 4, 5, 11), ("train_f30_c8_r2", 30, 8, 2, 6, 6, 5, 20, 12),
+             # kami's default width (options.def.yml: filters 64): the shapes the matrix-core training kernels tile for
+             ("train_f30_c64_r2", 30, 64, 2, 8, 8, 3, 5, 13))
+    only = [a.split("=", 1)[1] for a in sys.argv if a.startswith("--train-case=")]
+    for name, F, C, R, n, tbatch, epochs, mlr, seed in cases:
+        if only and name not in only:
+            continue
         rng = np.random.default_rng(seed)
         blob = W.random_weights(F, C, R, seed=seed, peaky=3.0)
         x = (rng.integers(0, 256, (n, 8, 8, F)).astype(np.float32) / 256.0)
