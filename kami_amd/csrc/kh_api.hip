@@ -1011,6 +1011,7 @@ int co_submit(kh_engine* e, int kind, const kh_board* boards, const float* plane
     for (; tid < KH_MAX_OUTSTANDING; ++tid)
         if (c->tickets[tid].state.load(std::memory_order_acquire) == 0) { t = &c->tickets[tid]; break; }
     if (!t) return fail(KH_ERR_INVALID, "%d submissions are outstanding on this engine: kh_wait for some before submitting more", KH_MAX_OUTSTANDING);
+    t->state.store(1, std::memory_order_relaxed);      // taken NOW: the wait for a free buffer below drops the lock
     CoBatch* b = nullptr;
     for (;;) {
         for (auto& x : c->batches)
@@ -1031,6 +1032,7 @@ int co_submit(kh_engine* e, int kind, const kh_board* boards, const float* plane
                     const size_t o_vals = (size_t)CO_ACTS * 4, o_flags = o_vals + (size_t)CO_ROWS * 4;
                     if (set_device(e) || b->pin_in.ensure(o_acts + (size_t)CO_ACTS * 4) || b->pin_out.ensure(o_flags + 16)) {
                         b->state = 0;
+                        t->state.store(0, std::memory_order_release);
                         return KH_ERR_HIP;
                     }
                     b->boards = reinterpret_cast<kh_board*>(b->pin_in.at(0));

@@ -604,8 +604,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                         const int brd = min(b0 + (bp >> 6), a.B - 1);
                         const float* row = a.in + ((size_t)brd * 64 + (bp & 63)) * F;
                         const int c = hh * 64 + 4 * (tid & 7);
-                        pl[hh][j][0] = *reinterpret_cast<const float4_u*>(row + min(c, F - 4));
-                        pl[hh][j][1] = *reinterpret_cast<const float4_u*>(row + min(c + 32, F - 4));
+                        // read-once stream: non-temporal, so that the XCD's L2 keeps the weight stream from one
+                        // launch to the next (25 MB of planes and policy pass through 32 MB of L2 per launch)
+                        pl[hh][j][0] = __builtin_nontemporal_load(reinterpret_cast<const float4_u*>(row + min(c, F - 4)));
+                        pl[hh][j][1] = __builtin_nontemporal_load(reinterpret_cast<const float4_u*>(row + min(c + 32, F - 4)));
                     }
                 __builtin_amdgcn_sched_barrier(0);
             }

@@ -61,6 +61,23 @@ class Ticket:
         return self._out
 
 
+# engines still open when the interpreter exits are closed while the HIP runtime is still up (module teardown order
+# is arbitrary otherwise, and an engine owns streams, launch-lane threads and device memory)
+import atexit
+import weakref
+
+_LIVE = weakref.WeakSet()
+
+
+@atexit.register
+def _close_all():
+    for nn in list(_LIVE):
+        try:
+            nn.close()
+        except Exception:
+            pass
+
+
 class NN:
     def __init__(self, width: int = 8, height: int = 8, features: int = NFEATURES,
                  psize: int = PSIZE, *, filters: int = 256, residuals: int = 2,
@@ -73,6 +90,7 @@ class NN:
         self.dtype = dtype
         self._h = C.c_void_p()
         _chk(self._lib.kh_create(C.byref(self.cfg), C.byref(self._h)))
+        _LIVE.add(self)
 
     # -- kami::NN surface ---------------------------------------------------------------
     def get_generation(self) -> int:
@@ -143,6 +161,7 @@ class NN:
         other._blob = self._blob
         other._h = C.c_void_p()
         _chk(self._lib.kh_clone(self._h, C.byref(other._h)))
+        _LIVE.add(other)
         return other
 
     # -- engine extras ------------------------------------------------------------------

@@ -178,7 +178,10 @@ class Pool:
         n = self.lib.ks_pool_drain_records(self.h, buf, cap)
         return buf[:n]
 
-    def __del__(self):
+    def close(self):
         if getattr(self, "h", None):
             self.lib.ks_pool_destroy(self.h)
             self.h = None
+
+    def __del__(self):
+        self.close()

@@ -529,6 +529,41 @@ def test_concurrent_small_callers_are_coalesced():
     assert rows > 0 and rows / launches > 16, (launches, rows)          # launches held more than one caller's batch
 
 
+def test_queue_under_buffer_pressure():
+    """Twelve threads keep two 300-position submissions each in flight with a launch target of 1 024: merge buffers
+    fill up (a submission that does not fit closes the batch) and submitters have to wait for one to come back from
+    the device.  A ticket is reserved before that wait (a free ticket found by two threads at once was round 2's
+    first bug in this queue: 'ticket already waited for'); every result equals the synchronous call's bits."""
+    import threading
+    F, C, R = 30, 64, 2
+    nn = NN(8, 8, F, 4672, filters=C, residuals=R, dtype="bf16", value_mode=L.KH_VALUE_PER_SAMPLE0)
+    nn.load_weights(W.random_weights(F, C, R, seed=4, peaky=10.0), 1)
+    cases = [_legal_case(300, 100 + i) for i in range(12)]
+    want = [nn.infer_legal(*c) for c in cases]
+    nn.set_coalesce(1024, 100)
+    errors = []
+
+    def work(i):
+        try:
+            for _ in range(30):
+                t1 = nn.submit_infer_legal(*cases[i])
+                t2 = nn.submit_infer_legal(*cases[i])
+                for t in (t1, t2):
+                    p, v = t.wait()
+                    if not (np.array_equal(p, want[i][0]) and np.array_equal(v, want[i][1])):
+                        errors.append((i, "bits"))
+        except Exception as e:                      # noqa: BLE001
+            errors.append((i, repr(e)))
+
+    th = [threading.Thread(target=work, args=(i,)) for i in range(len(cases))]
+    [t.start() for t in th]
+    [t.join() for t in th]
+    nn.set_coalesce(0, 0)
+    assert not errors, errors[:3]
+    launches, rows = nn.coalesce_stats()
+    assert rows == 12 * 30 * 2 * 300 and rows / launches > 300
+
+
 def test_weight_swap_while_threads_infer():
     """nn.cpp:166,206: read() replaces the weights while inference threads are inside infer().  Here the swap is atomic
     and never stalls a caller: six threads keep calling (directly and through the queue) while the main thread swaps
