@@ -186,8 +186,10 @@ int  kh_encode_infer_legal(kh_engine* e, const kh_board* boards, int batch,
  * valid and untouched until kh_wait returns.  At most KH_MAX_OUTSTANDING tickets per engine may be un-waited: one more
  * kh_submit_* returns KH_ERR_INVALID (it never blocks on the caller's own outstanding work).  A submission holds at most
  * 512 positions (kh_submit_encode_infer_legal) / 128 positions (kh_submit_infer); larger batches gain nothing from
- * merging and take the synchronous calls.  The synchronous kh_infer / kh_encode_infer_legal use this queue themselves
- * whenever several small calls are inside the engine at the same moment, and the private-slot path otherwise. */
+ * merging and take the synchronous calls.  The synchronous kh_encode_infer_legal uses this queue itself whenever
+ * several small calls are inside the engine at the same moment (its payload is ~200 B per position: the launch is
+ * what costs), and the private-slot path otherwise; kh_infer always keeps its private slot (26-49 KB per position
+ * over PCIe: concurrent callers' own streams overlap that better than a merged launch). */
 #define KH_MAX_OUTSTANDING 64
 int  kh_submit_infer(kh_engine* e, const float* input, int batch, float* policy, float* value, int64_t* ticket);
 int  kh_submit_encode_infer_legal(kh_engine* e, const kh_board* boards, int batch,

@@ -533,6 +533,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 // LDS operations are ordered; its MFMAs have all read the old image by then) — and the weight ring simply runs on
 // through all (1 + 2R) x 36 chunks.  Same reduction order and epilogue arithmetic as the per-layer kernels: same bits.
 struct Tower128Args {
+    const float* planes;          // fp32 [B][64][F] (nn.cpp:157), converted while they are staged; nullptr: take `in`
+    int F;                        // planes per pixel, <= 128
+    unsigned magic;               // ceil(2^32 / F): e / F = umulhi(e, magic) for e < 64 * 128
     const unsigned short* in;     // T [B][64][128]: the planes, converted and zero-padded (planes_to_act_kernel)
     const unsigned short* w;      // (1 + 2R) layers x 36 chunks of 8 KB, pack_layer_wide128 order (Co = Ci = 128)
     const float* shift;           // (1 + 2R) x 128 folded BatchNorm shifts
@@ -560,6 +563,41 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 
 #pragma unroll
     for (int i = 0; i < RDN - 1; ++i) ring_issue<RDN>(stream, NCHT, i, wave, lane);
+    if (a.planes) {
+        // fp32 planes straight from the caller's tensor (no planes_to_act launch, no T copy in HBM): a board is
+        // 64 F contiguous floats, 16-byte aligned, read as float4 pieces whose four elements may straddle pixels;
+        // every element is rounded to T and written to (pixel, plane) of the image.  The whole image is zeroed first
+        // (halo, and planes F..127 of the padded stem).
+        const u32x4 z = { 0, 0, 0, 0 };
+        for (int i = tid; i < 4 * board_bytes / 16; i += 256) *reinterpret_cast<u32x4*>(img + i * 16) = z;
+        const int F = a.F, pieces = 16 * F;                 // float4 pieces per board
+        constexpr int NU = 32;                               // 4 boards x 16 F pieces / 256 threads <= 32 for F <= 128
+        float4 v[NU];
+#pragma unroll
+        for (int u = 0; u < NU; ++u) {
+            const int i = tid + u * 256;
+            const int bb = __umulhi((unsigned)i, a.magic) >> 4;          // i / (16 F)
+            const int q = i - bb * pieces;
+            v[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (bb < 4 && b0 + bb < a.B) v[u] = *reinterpret_cast<const float4*>(a.planes + ((size_t)(b0 + bb) * 64) * F + 4 * q);
+        }
+        __syncthreads();                                     // the zeroes are in place before anybody writes planes over them
+#pragma unroll
+        for (int u = 0; u < NU; ++u) {
+            const int i = tid + u * 256;
+            const int bb = __umulhi((unsigned)i, a.magic) >> 4;
+            if (bb >= 4) continue;
+            const int q = i - bb * pieces;
+            int p = __umulhi((unsigned)(4 * q), a.magic), c = 4 * q - p * F;
+            const float e[4] = { v[u].x, v[u].y, v[u].z, v[u].w };
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int pix = ((p >> 3) + 1) * PITCH + (p & 7) + 1;
+                *reinterpret_cast<unsigned short*>(img + bb * board_bytes + pix * stride + c * 2) = to_bits<T>(e[k]);
+                if (++c == F) { c = 0; ++p; }
+            }
+        }
+    } else {
     {
         const u32x4 z = { 0, 0, 0, 0 };
         constexpr int per_px = stride / 16;
@@ -586,6 +624,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             const int pix = ((p >> 3) + 1) * PITCH + (p & 7) + 1;
             *reinterpret_cast<u32x4*>(img + bb * board_bytes + pix * stride + c * 16) = v[u];
         }
+    }
     }
     const int lp = PIXMAP[lane & 31];
     const int py = lp >> 3, px = lp & 7;
@@ -1164,7 +1203,12 @@ template <typename T> static hipError_t run(const LayersArgs& L, hipStream_t s)
     const long npix = (long)L.B * 64;
     int blocks = (int)((npix * (L.FP / 8) + 255) / 256);
     if (blocks > 4096) blocks = 4096;
-    hipLaunchKernelGGL(planes_to_act_kernel<T>, dim3(blocks), dim3(256), 0, s, L.in, L.act_in, npix, L.F, L.FP);
+    static const int force = getenv("KAMI_WIDE_VARIANT") ? atoi(getenv("KAMI_WIDE_VARIANT")) : 0;
+    // 128 planes (padded) and 128 filters: the whole 3x3 stack in one launch, activations on chip (tower128_kernel),
+    // reading the fp32 planes itself.  One workgroup per four boards: worth it once that keeps most CUs busy.
+    const bool fused = L.FP == 128 && L.CP == 128 && L.w4 && L.w4_off[0] != (size_t)-1 && (force == 5 || (!force && L.B >= 640));
+    const bool direct = fused && (reinterpret_cast<uintptr_t>(L.in) & 15) == 0;
+    if (!direct) hipLaunchKernelGGL(planes_to_act_kernel<T>, dim3(blocks), dim3(256), 0, s, L.in, L.act_in, npix, L.F, L.FP);
     unsigned short *x = L.act[0], *t = L.act[1], *u = L.act[2];
     hipError_t e;
     size_t li = 0;
@@ -1173,10 +1217,6 @@ template <typename T> static hipError_t run(const LayersArgs& L, hipStream_t s)
     auto shift = [&](int idx) { return L.shift + L.shift_off[idx]; };
     ConvArgs a;
     a.B = L.B;
-    // 128 planes (padded) and 128 filters: the whole 3x3 stack in one launch, activations on chip (tower128_kernel).
-    // One workgroup per four boards: worth it once that keeps a good part of the CUs busy.
-    static const int force = getenv("KAMI_WIDE_VARIANT") ? atoi(getenv("KAMI_WIDE_VARIANT")) : 0;
-    const bool fused = L.FP == 128 && L.CP == 128 && L.w4 && layer4(0) && (force == 5 || (!force && L.B >= 384));
     if (fused) {
         static std::atomic<bool> attr_done{ false };
         if (!attr_done.load(std::memory_order_acquire)) {
@@ -1184,6 +1224,7 @@ template <typename T> static hipError_t run(const LayersArgs& L, hipStream_t s)
             attr_done.store(true, std::memory_order_release);
         }
         Tower128Args t8;
+        t8.planes = direct ? L.in : nullptr; t8.F = L.F; t8.magic = (unsigned)((0x100000000ull + L.F - 1) / L.F);
         t8.in = L.act_in; t8.w = layer4(0); t8.shift = shift(0); t8.out = x; t8.B = L.B; t8.R = L.R;
         hipLaunchKernelGGL((tower128_kernel<T>), dim3((L.B + 3) / 4), dim3(256), 4 * CHUNKB + 4 * NPIX * (128 * 2 + 16), s, t8);
         if ((e = hipGetLastError()) != hipSuccess) return e;
