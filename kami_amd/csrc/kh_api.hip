@@ -130,6 +130,8 @@ struct Weights {
     // per-layer MFMA path for wide nets (layers_mfma.hip)
     DevMem ly_w, ly_shift, ly_misc;      // ly_misc: vw[CP], fcw[256*64], fcb[256]
     DevMem ly_w4;                        // 3x3 layers once more, packed for conv4_mfma_kernel
+    DevMem ly_wh;                        // policyconv + policyconv2 packed for policy_head4_kernel
+    bool ly_wh_ok = false;
     std::vector<size_t> ly_w_off, ly_shift_off, ly_w4_off;
     int ly_FP = 0, ly_CP = 0;
     float ly_vshift = 0.0f;
@@ -299,6 +301,12 @@ int build_layers(Weights& W, const HostNet& n, int dtype, int F, int C, int R)
     for (int i = 0; i < 2 * R; ++i) add(n.res[i].w, &n.res[i], nullptr, C, C, 9, CP, CP);
     add(n.pconv.w, &n.pconv, nullptr, KH_POLICY_MID, C, 1, KH_POLICY_MID, CP);
     add(n.p2w, nullptr, n.p2b, KH_POLICY_PLANES, KH_POLICY_MID, 1, 128, KH_POLICY_MID);
+    std::vector<uint16_t> wh;
+    if (!f32 && (CP == 128 || CP == 256)) {          // policy_head4_kernel's shapes
+        fold_bn(n.pconv, KH_POLICY_MID, sc.data(), sh.data());
+        pack_layer_wide128(wh, dtype, n.pconv.w, sc.data(), KH_POLICY_MID, C, 1, KH_POLICY_MID, CP);
+        pack_layer_wide128(wh, dtype, n.p2w, nullptr, KH_POLICY_PLANES, KH_POLICY_MID, 1, 128, KH_POLICY_MID);
+    }
     std::vector<float> misc((size_t)CP + KH_VALUE_WIDTH * 64 + KH_VALUE_WIDTH, 0.0f);
     float vs, vsh;
     fold_bn(n.vconv, 1, &vs, &vsh);
@@ -313,6 +321,11 @@ int build_layers(Weights& W, const HostNet& n, int dtype, int F, int C, int R)
     if (!w4.empty()) {
         if (W.ly_w4.ensure(w4.size() * 2)) return KH_ERR_HIP;
         HIPCHK(hipMemcpy(W.ly_w4.p, w4.data(), w4.size() * 2, hipMemcpyHostToDevice));
+    }
+    if (!wh.empty()) {
+        if (W.ly_wh.ensure(wh.size() * 2)) return KH_ERR_HIP;
+        HIPCHK(hipMemcpy(W.ly_wh.p, wh.data(), wh.size() * 2, hipMemcpyHostToDevice));
+        W.ly_wh_ok = true;
     }
     HIPCHK(hipMemcpy(W.ly_shift.p, shift.data(), shift.size() * 4, hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(W.ly_misc.p, misc.data(), misc.size() * 4, hipMemcpyHostToDevice));
@@ -599,9 +612,10 @@ int forward_layers(kh_engine* e, const Weights& W, Slot& s, const float* d_in, i
     L.w4 = W.ly_w4.as<unsigned short>(); L.w4_off = W.ly_w4_off.data();
     L.shift = W.ly_shift.as<float>(); L.shift_off = W.ly_shift_off.data();
     L.vw = W.ly_misc.as<float>(); L.vshift = W.ly_vshift;
-    HIPCHK(kh::launch_layers(e->cfg.dtype, L, st));
+    L.wh = W.ly_wh_ok ? W.ly_wh.as<unsigned short>() : nullptr;
+    L.policy = d_policy; L.flags = flags; L.want_logits = d_logits_out != nullptr;
+    HIPCHK(kh::launch_layers(e->cfg.dtype, L, st));                                             // ... and the softmax, nn.cpp:80
     const float* fcw = W.ly_misc.as<float>() + W.ly_CP;
-    kh::launch_softmax4672(L.logits, d_policy, B, flags, st);                                   // nn.cpp:80
     kh::launch_value_fc(L.v64, fcw, fcw + (size_t)KH_VALUE_WIDTH * 64, d_vfull, B, flags, st);   // nn.cpp:86-88
     HIPCHK(hipGetLastError());
     return KH_OK;

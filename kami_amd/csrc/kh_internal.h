@@ -82,6 +82,10 @@ struct LayersArgs {
     const size_t* shift_off;       // HOST array: float offset of each layer in shift
     const float* vw;               // [CP] valueconv weight * bn scale (device)
     float vshift;
+    const unsigned short* wh;      // policy head packed for policy_head4_kernel (device; nullptr: not eligible)
+    float* policy;                 // [B][4672]: launch_layers runs the softmax itself (nn.cpp:80)
+    int* flags;                    // NaN flags ([0] policy, [1] value)
+    bool want_logits;              // the caller asked for the pre-softmax logits in `logits`
 };
 size_t layers_lds_bytes(int Ci);
 // exact-fp32 MFMA convolution (conv_f32_kernel) for the trainer: out [B][64][Co] = conv(in [B][64][Ci]) + bias (nullable),

@@ -18,6 +18,7 @@
 #include <algorithm>
 #include <atomic>
 #include <cstdlib>
+#include <type_traits>
 
 namespace kh {
 namespace lay {
@@ -54,6 +55,15 @@ template <typename T> __device__ __forceinline__ unsigned short to_bits(float v)
 }
 template <typename T> __device__ __forceinline__ float from_bits(unsigned short u) { return (float)__builtin_bit_cast(T, u); }
 __device__ __forceinline__ float relu_keep_nan(float v) { return v < 0.0f ? 0.0f : v; }   // torch::relu semantics
+// two floats -> one register of two T (round to nearest even, the same values as two to_bits<T>): ONE
+// v_cvt_pk_bf16_f32 / v_cvt_pk_f16_f32 instead of two scalar converts and a merge
+template <typename T> __device__ __forceinline__ unsigned pack2(float a, float b)
+{
+    using f32x2 = __attribute__((ext_vector_type(2))) float;
+    using t2 = __attribute__((ext_vector_type(2))) T;
+    const t2 r = __builtin_convertvector(f32x2{ a, b }, t2);
+    return __builtin_bit_cast(unsigned, r);
+}
 
 // fp32 planes [B][64][F] -> T [B][64][FP] (channels >= F zero).  One thread per 8-channel chunk.
 template <typename T>
@@ -361,7 +371,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, RDN == 2
 template <typename T, int EPI, int NP>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void conv4_mfma_kernel(ConvArgs a)
 {
-    constexpr int RDN = 4, TAPS = 9;
+    constexpr int RDN = 4;
+    [[maybe_unused]] constexpr int TAPS = 9;              // WIDE_STAMP's condition
     constexpr int LDS_IMG = RDN * CHUNKB;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     using V = typename Elem<T>::vec8;
@@ -506,8 +517,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                     v[0] += from_bits<T>((unsigned short)(sk.x & 0xffff)); v[1] += from_bits<T>((unsigned short)(sk.x >> 16));
                     v[2] += from_bits<T>((unsigned short)(sk.y & 0xffff)); v[3] += from_bits<T>((unsigned short)(sk.y >> 16));
                 }
-                pk[g][0] = to_bits<T>(v[0]) | ((unsigned)to_bits<T>(v[1]) << 16);
-                pk[g][1] = to_bits<T>(v[2]) | ((unsigned)to_bits<T>(v[3]) << 16);
+                pk[g][0] = pack2<T>(v[0], v[1]);
+                pk[g][1] = pack2<T>(v[2], v[3]);
             }
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
@@ -532,6 +543,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 // operand the per-layer path re-reads from HBM), round, write the board's next input image in place (the wave's own
 // LDS operations are ordered; its MFMAs have all read the old image by then) — and the weight ring simply runs on
 // through all (1 + 2R) x 36 chunks.  Same reduction order and epilogue arithmetic as the per-layer kernels: same bits.
+#ifdef KAMI_WIDE_DIAG
+// diagnostic build only: per layer, wave 0 of the first 256 workgroups stamps loop start / loop end / boundary end
+__device__ unsigned long long g_t128_stamps[256 * 64 * 4];
+#define T128_STAMP(l, k) do { if (tid == 0 && blockIdx.x < 256 && (l) < 64) g_t128_stamps[(blockIdx.x * 64 + (l)) * 4 + (k)] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define T128_STAMP(l, k) do {} while (0)
+#endif
+
 struct Tower128Args {
     const float* planes;          // fp32 [B][64][F] (nn.cpp:157), converted while they are staged; nullptr: take `in`
     int F;                        // planes per pixel, <= 128
@@ -633,20 +652,31 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     // where this lane's outputs go in its board's image: centre of the 3x3 window, its 4-channel groups
     char* const w_base = smem + LDS_IMG + wave * board_bytes + ((py + 1) * PITCH + px + 1) * stride + h * 8;
     f32x16 acc[8];
-    auto load_shift = [&](int l) {
+    // the next layer's 64 shift values of this lane: requested two steps before a layer ends (16 loads, L2), so the
+    // boundary finds them in registers instead of waiting out a round trip behind the ring's pieces
+    float4 sh[16];
+    auto request_shift = [&](int l) {
+        const int lc = l < NL ? l : NL - 1;                 // past the last layer: a harmless re-read
+#pragma unroll
+        for (int ms = 0; ms < 4; ++ms)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) sh[ms * 4 + g] = *reinterpret_cast<const float4*>(a.shift + lc * 128 + ms * 32 + 8 * g + 4 * h);
+    };
+    auto shift_to_acc = [&]() {
 #pragma unroll
         for (int ms = 0; ms < 4; ++ms)
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
-                const float4 s = *reinterpret_cast<const float4*>(a.shift + l * 128 + ms * 32 + 8 * g + 4 * h);
+                const float4 s4 = sh[ms * 4 + g];
 #pragma unroll
                 for (int hp = 0; hp < 2; ++hp) {
-                    acc[ms * 2 + hp][4 * g + 0] = s.x; acc[ms * 2 + hp][4 * g + 1] = s.y;
-                    acc[ms * 2 + hp][4 * g + 2] = s.z; acc[ms * 2 + hp][4 * g + 3] = s.w;
+                    acc[ms * 2 + hp][4 * g + 0] = s4.x; acc[ms * 2 + hp][4 * g + 1] = s4.y;
+                    acc[ms * 2 + hp][4 * g + 2] = s4.z; acc[ms * 2 + hp][4 * g + 3] = s4.w;
                 }
             }
     };
-    load_shift(0);
+    request_shift(0);
+    shift_to_acc();
     auto chunk_off = [](int n) -> unsigned {
         const int q = n / 18, tap = (n % 18) >> 1, half = n & 1;
         return (unsigned)(((tap / 3) * PITCH + (tap % 3)) * stride) + q * 128 + half * 64;
@@ -664,7 +694,32 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 #pragma unroll
         for (int f = 0; f < 8; ++f) A[0][f] = *reinterpret_cast<const V*>(smem + a_off + f * 1024);
     }
+    // ---- layer boundary (this wave's board only), one straight-line copy per kind so that nothing in it branches:
+    // KIND 0: stem (nn.cpp:63-65): becomes the residual stream; 1: a block's first conv (nn.cpp:30); 2: its second conv,
+    // ReLU before the add of the stream, none after (nn.cpp:31-33): becomes the new stream
+    auto boundary = [&](auto kind) {
+        constexpr int KIND = decltype(kind)::value;
+#pragma unroll
+        for (int hp = 0; hp < 2; ++hp)
+#pragma unroll
+            for (int ms = 0; ms < 4; ++ms)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    float v[4];
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) v[i] = relu_keep_nan(acc[ms * 2 + hp][4 * g + i]);
+                    if (KIND == 2) {
+                        const unsigned s0 = xr[ms * 2 + hp][g][0], s1 = xr[ms * 2 + hp][g][1];
+                        v[0] += from_bits<T>((unsigned short)(s0 & 0xffff)); v[1] += from_bits<T>((unsigned short)(s0 >> 16));
+                        v[2] += from_bits<T>((unsigned short)(s1 & 0xffff)); v[3] += from_bits<T>((unsigned short)(s1 >> 16));
+                    }
+                    const unsigned p0 = pack2<T>(v[0], v[1]), p1 = pack2<T>(v[2], v[3]);
+                    if (KIND != 1) { xr[ms * 2 + hp][g][0] = p0; xr[ms * 2 + hp][g][1] = p1; }
+                    *reinterpret_cast<u32x2*>(w_base + hp * HALF + (ms * 32 + 8 * g) * 2) = u32x2{ p0, p1 };   // (after the last layer: unused)
+                }
+    };
     for (int l = 0; l < NL; ++l) {
+        T128_STAMP(l, 0);
 #pragma unroll
         for (int k = 0; k < 2; ++k)
 #pragma unroll
@@ -676,6 +731,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(2 * (RDN - 3)) : "memory");
             __builtin_amdgcn_sched_barrier(0);
             ring_issue<RDN>(stream, NCHT, g + RDN - 1, wave, lane);
+            if (n == NCH - 2) request_shift(l + 1);
             const unsigned a_off = (unsigned)(((n + 1) % RDN) * CHUNKB) + lane * 16;      // 36 chunks per layer: slot = n % 4
 #pragma unroll
             for (int f = 0; f < 8; ++f) A[nxt][f] = *reinterpret_cast<const V*>(smem + a_off + f * 1024);
@@ -691,6 +747,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                 for (int ms = 0; ms < 4; ++ms)
 #pragma unroll
                     for (int hp = 0; hp < 2; ++hp) acc[ms * 2 + hp] = Elem<T>::mfma(A[cur][k * 4 + ms], Bq[cur][k * 2 + hp], acc[ms * 2 + hp]);
+            if (n == NCH - 2) __builtin_amdgcn_sched_group_barrier(0x020, 16, 0);       // the shift loads first: they have two steps to land
 #pragma unroll
             for (int i = 0; i < 12; ++i) {
                 __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
@@ -698,29 +755,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             }
             __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
         }
-        // ---- layer boundary (this wave's board only).  l = 0: stem (nn.cpp:63-65); odd l: a block's first conv
-        // (nn.cpp:30); even l > 0: its second conv, ReLU before the add, none after (nn.cpp:31-33)
-        const bool add_skip = l > 0 && (l & 1) == 0, keep = (l & 1) == 0, last = l + 1 == NL;
-#pragma unroll
-        for (int hp = 0; hp < 2; ++hp)
-#pragma unroll
-            for (int ms = 0; ms < 4; ++ms)
-#pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    float v[4];
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) v[i] = relu_keep_nan(acc[ms * 2 + hp][4 * g + i]);
-                    if (add_skip) {
-                        const unsigned s0 = xr[ms * 2 + hp][g][0], s1 = xr[ms * 2 + hp][g][1];
-                        v[0] += from_bits<T>((unsigned short)(s0 & 0xffff)); v[1] += from_bits<T>((unsigned short)(s0 >> 16));
-                        v[2] += from_bits<T>((unsigned short)(s1 & 0xffff)); v[3] += from_bits<T>((unsigned short)(s1 >> 16));
-                    }
-                    const unsigned p0 = to_bits<T>(v[0]) | ((unsigned)to_bits<T>(v[1]) << 16);
-                    const unsigned p1 = to_bits<T>(v[2]) | ((unsigned)to_bits<T>(v[3]) << 16);
-                    if (keep) { xr[ms * 2 + hp][g][0] = p0; xr[ms * 2 + hp][g][1] = p1; }
-                    if (!last) *reinterpret_cast<u32x2*>(w_base + hp * HALF + (ms * 32 + 8 * g) * 2) = u32x2{ p0, p1 };
-                }
-        if (!last) load_shift(l + 1);
+        T128_STAMP(l, 1);
+        if (l == 0) boundary(std::integral_constant<int, 0>{});
+        else if (l & 1) boundary(std::integral_constant<int, 1>{});
+        else boundary(std::integral_constant<int, 2>{});
+        T128_STAMP(l, 3);
+        shift_to_acc();
+        T128_STAMP(l, 2);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // drain the ring (tail re-fetches) before exit
 
@@ -739,6 +780,201 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                 const auto s1 = __builtin_amdgcn_permlane32_swap(xr[ms * 2 + hp][2 * j][1], xr[ms * 2 + hp][2 * j + 1][1], false, false);
                 const u32x4 o = { s0[0], s1[0], s0[1], s1[1] };
                 *reinterpret_cast<u32x4*>(a.out + row + ms * 32 + 16 * j + 8 * h) = o;
+            }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// policy_head4_kernel — the whole policy head (nn.cpp:72-80) of four boards per workgroup in one launch:
+// policyconv 1x1 (C -> 128) + pbatchnorm + ReLU, policyconv2 1x1 (128 -> 73) + bias, softmax over the board's 4 672
+// logits, policy row out.  conv4's tiling again: a wave owns one board and all output channels, so the 128-channel
+// intermediate goes back into the wave's own image (no HBM, no barrier) and the softmax is a WAVE reduction over the
+// 8 accumulators (planes >= 73 are padding).  Replaces three launches that moved 16.8 MB (intermediate) + 2 x 19 MB
+// (fp32 logits written, then read by the softmax) per 1 024 boards for 6.6 MFLOP per board.  The convolutions walk
+// the reduction in conv_mfma_kernel's order (logits bit-identical); the softmax sums in another order than
+// softmax4672_kernel, and is used at every batch size of a configuration, so batch splits still agree bit for bit.
+struct Head4Args {
+    const unsigned short* x;      // T [B][64][Ci], Ci = NP * 128
+    const unsigned short* w;      // policyconv chunks (Ci / 32 of 8 KB) then policyconv2 chunks (4), pack_layer_wide128 order
+    const float* shift1;          // [128] folded pbatchnorm shift
+    const float* bias2;           // [128] policyconv2 bias, planes >= 73 zero
+    float* policy;                // [B][4672]
+    float* logits;                // nullable [B][4672]
+    int* flags;                   // [0]: a NaN in some policy row (nn.cpp:176-177)
+    int B;
+};
+
+__device__ __forceinline__ float wave_max_f(float v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+__device__ __forceinline__ float wave_sum_f(float v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+template <typename T, int NP>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void policy_head4_kernel(Head4Args a)
+{
+    constexpr int RDN = 4;
+    constexpr int LDS_IMG = RDN * CHUNKB;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    using V = typename Elem<T>::vec8;
+    const int tid = threadIdx.x, lane = tid & 63, h = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    constexpr int Ci = 128, CiTot = NP * Ci;
+    constexpr int stride = Ci * 2 + 16;
+    constexpr int board_bytes = 64 * stride;               // 1x1 convolutions: no halo
+    const int b0 = blockIdx.x * 4;
+    constexpr int NC1 = NP * 4, NCHT = NC1 + 4;
+    const char* stream = reinterpret_cast<const char*>(a.w);
+    char* img = smem + LDS_IMG;
+#pragma unroll
+    for (int i = 0; i < RDN - 1; ++i) ring_issue<RDN>(stream, NCHT, i, wave, lane);
+    auto stage = [&](int pass) {
+        const unsigned short* src = a.x + pass * Ci;
+        u32x4 v[16];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) {
+            const int i = tid + u * 256;
+            const int bb = i >> 10, p = (i >> 4) & 63, c = i & 15;
+            v[u] = u32x4{ 0, 0, 0, 0 };
+            if (b0 + bb < a.B) v[u] = *reinterpret_cast<const u32x4*>(src + ((size_t)(b0 + bb) * 64 + p) * CiTot + c * 8);
+        }
+#pragma unroll
+        for (int u = 0; u < 16; ++u) {
+            const int i = tid + u * 256;
+            const int bb = i >> 10, p = (i >> 4) & 63, c = i & 15;
+            *reinterpret_cast<u32x4*>(img + bb * board_bytes + p * stride + c * 16) = v[u];
+        }
+    };
+    const int lp = PIXMAP[lane & 31];                       // this lane's pixel within a 32-pixel half
+    const unsigned b_base = LDS_IMG + wave * board_bytes + lp * stride + h * 16;
+    constexpr unsigned HALF = 32 * stride;
+    char* const w_base = smem + LDS_IMG + wave * board_bytes + lp * stride + h * 8;
+    f32x16 acc[8];
+    auto init_acc = [&](const float* sh) {
+#pragma unroll
+        for (int ms = 0; ms < 4; ++ms)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const float4 s4 = *reinterpret_cast<const float4*>(sh + ms * 32 + 8 * g + 4 * h);
+#pragma unroll
+                for (int hp = 0; hp < 2; ++hp) {
+                    acc[ms * 2 + hp][4 * g + 0] = s4.x; acc[ms * 2 + hp][4 * g + 1] = s4.y;
+                    acc[ms * 2 + hp][4 * g + 2] = s4.z; acc[ms * 2 + hp][4 * g + 3] = s4.w;
+                }
+            }
+    };
+    init_acc(a.shift1);
+    auto chunk_off = [](int n) -> unsigned { return (unsigned)((n >> 1) * 128 + (n & 1) * 64); };   // slice, half of the slice
+    V A[2][8], Bq[2][4];
+    // four chunk steps: conv1's of one pass (G0 = 4 * pass), or conv2's (G0 = NC1)
+    auto four_steps = [&](int G0) {
+#pragma unroll
+        for (int k = 0; k < 2; ++k)
+#pragma unroll
+            for (int hp = 0; hp < 2; ++hp) Bq[0][k * 2 + hp] = *reinterpret_cast<const V*>(smem + b_base + hp * HALF + chunk_off(0) + k * 32);
+#pragma unroll
+        for (int n = 0; n < 4; ++n) {
+            const int cur = n & 1, nxt = cur ^ 1, g = G0 + n;
+            asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(2 * (RDN - 3)) : "memory");
+            __builtin_amdgcn_sched_barrier(0);
+            ring_issue<RDN>(stream, NCHT, g + RDN - 1, wave, lane);
+            const unsigned a_off = (unsigned)(((n + 1) % RDN) * CHUNKB) + lane * 16;       // 4 chunks per call: slot = n
+#pragma unroll
+            for (int f = 0; f < 8; ++f) A[nxt][f] = *reinterpret_cast<const V*>(smem + a_off + f * 1024);
+            if (n + 1 < 4) {
+#pragma unroll
+                for (int k = 0; k < 2; ++k)
+#pragma unroll
+                    for (int hp = 0; hp < 2; ++hp) Bq[nxt][k * 2 + hp] = *reinterpret_cast<const V*>(smem + b_base + hp * HALF + chunk_off(n + 1) + k * 32);
+            }
+#pragma unroll
+            for (int k = 0; k < 2; ++k)
+#pragma unroll
+                for (int ms = 0; ms < 4; ++ms)
+#pragma unroll
+                    for (int hp = 0; hp < 2; ++hp) acc[ms * 2 + hp] = Elem<T>::mfma(A[cur][k * 4 + ms], Bq[cur][k * 2 + hp], acc[ms * 2 + hp]);
+#pragma unroll
+            for (int i = 0; i < 12; ++i) {
+                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            }
+            __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+        }
+    };
+#pragma unroll
+    for (int pass = 0; pass < NP; ++pass) {
+        if (pass > 0) __syncthreads();
+        stage(pass);
+        asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(2 * (RDN - 2)) : "memory");
+        if (pass == 0) {
+#pragma unroll
+            for (int f = 0; f < 8; ++f) A[0][f] = *reinterpret_cast<const V*>(smem + lane * 16 + f * 1024);
+        }
+        four_steps(pass * 4);
+    }
+    // policyconv's output (pbatchnorm folded, ReLU, rounded to T like the per-layer path's intermediate) -> this wave's image
+#pragma unroll
+    for (int hp = 0; hp < 2; ++hp)
+#pragma unroll
+        for (int ms = 0; ms < 4; ++ms)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                float v[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) v[i] = relu_keep_nan(acc[ms * 2 + hp][4 * g + i]);
+                *reinterpret_cast<u32x2*>(w_base + hp * HALF + (ms * 32 + 8 * g) * 2) = u32x2{ pack2<T>(v[0], v[1]), pack2<T>(v[2], v[3]) };
+            }
+    init_acc(a.bias2);
+    four_steps(NC1);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // drain the ring (tail re-fetches) before exit
+
+    // ---- softmax over the board's 64 pixels x 73 planes (nn.cpp:78-80: exp(log_softmax)), all inside this wave
+    const int b = b0 + wave;
+    float m = -INFINITY;
+    bool nan = false;
+#pragma unroll
+    for (int i8 = 0; i8 < 8; ++i8)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int ch = (i8 >> 1) * 32 + 8 * (r >> 2) + 4 * h + (r & 3);
+            if (ch < KH_POLICY_PLANES) { const float v = acc[i8][r]; nan |= (v != v); m = fmaxf(m, v); }
+        }
+    m = wave_max_f(m);
+    float sum = 0.0f;
+#pragma unroll
+    for (int i8 = 0; i8 < 8; ++i8)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int ch = (i8 >> 1) * 32 + 8 * (r >> 2) + 4 * h + (r & 3);
+            if (ch < KH_POLICY_PLANES) sum += expf(acc[i8][r] - m);
+        }
+    sum = wave_sum_f(sum);
+    const float ls = logf(sum);
+    const bool row_nan = __any(nan);                        // any NaN logit poisons the whole row in the reference
+    if (b >= a.B) return;
+    if (row_nan && lane == 0) atomicOr(&a.flags[0], 1);
+#pragma unroll
+    for (int hp = 0; hp < 2; ++hp) {
+        const int pix = 32 * hp + lp;
+        float* po = a.policy + (size_t)b * KH_PSIZE + pix * KH_POLICY_PLANES;
+        float* lo = a.logits ? a.logits + (size_t)b * KH_PSIZE + pix * KH_POLICY_PLANES : nullptr;
+#pragma unroll
+        for (int ms = 0; ms < 3; ++ms)                      // planes 96..127 are padding
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int ch = ms * 32 + 8 * (r >> 2) + 4 * h + (r & 3);
+                if (ch < KH_POLICY_PLANES) {
+                    const float v = acc[ms * 2 + hp][r];
+                    po[ch] = row_nan ? NAN : expf((v - m) - ls);
+                    if (lo) lo[ch] = v;
+                }
             }
     }
 }
@@ -936,8 +1172,6 @@ __global__ __launch_bounds__(256) void conv_f32_small_kernel(ConvArgsF32 a)
     const int Ci = a.Ci, Co = a.Co;
     const int CS = Ci < 128 ? Ci : 128;
     const int stride = CS * 4 + 16;
-    const int npx = (TAPS == 9) ? NPIX : 64;
-    const int board_bytes = npx * stride;
     const int b = blockIdx.x, cb = blockIdx.y;           // cb: 32-channel block
     const int ph = wave & 1, kh = wave >> 1;
     if (TAPS == 9) {
@@ -1121,6 +1355,7 @@ static hipError_t run_f32(const LayersArgs& L, hipStream_t s)
     if ((e = launch_conv_f32<1, 0>(a, s)) != hipSuccess) return e;
     a.in = reinterpret_cast<const float*>(L.pmid); a.w = wbase + L.w_off[li]; a.shift = L.shift + L.shift_off[li]; a.out = L.logits; a.Ci = KH_POLICY_MID; a.Co = 128; ++li;
     if ((e = launch_conv_f32<1, 2>(a, s)) != hipSuccess) return e;
+    launch_softmax4672(L.logits, L.policy, L.B, L.flags, s);                  // nn.cpp:80
     int vb = (int)((npix + 255) / 256);
     if (vb > 4096) vb = 4096;
     hipLaunchKernelGGL(value_conv_f32_kernel, dim3(vb), dim3(256), 0, s, x, L.vw, L.vshift, L.v64, npix, L.CP);
@@ -1242,12 +1477,31 @@ template <typename T> static hipError_t run(const LayersArgs& L, hipStream_t s)
         if ((e = launch_conv<T, 9, 1>(a, s)) != hipSuccess) return e;
         unsigned short* tmp = x; x = u; u = tmp;
     }
-    // policy head                                                           nn.cpp:72-79
+    // policy head                                                           nn.cpp:72-80
     a.w4 = nullptr;
+    if (L.wh && (L.CP == 128 || L.CP == 256)) {
+        // conv + BN + ReLU, conv + bias and the softmax of four boards per workgroup in one launch
+        Head4Args hd;
+        hd.x = x; hd.w = L.wh; hd.shift1 = shift(li); hd.bias2 = shift(li + 1); hd.policy = L.policy; hd.logits = L.want_logits ? L.logits : nullptr;
+        hd.flags = L.flags; hd.B = L.B;
+        li += 2;
+        const int lds = 4 * CHUNKB + 4 * 64 * (128 * 2 + 16);
+        static std::atomic<bool> attr_done{ false };
+        if (!attr_done.load(std::memory_order_acquire)) {
+            if ((e = hipFuncSetAttribute(reinterpret_cast<const void*>(&policy_head4_kernel<T, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)) != hipSuccess) return e;
+            if ((e = hipFuncSetAttribute(reinterpret_cast<const void*>(&policy_head4_kernel<T, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)) != hipSuccess) return e;
+            attr_done.store(true, std::memory_order_release);
+        }
+        if (L.CP == 128) hipLaunchKernelGGL((policy_head4_kernel<T, 1>), dim3((L.B + 3) / 4), dim3(256), lds, s, hd);
+        else hipLaunchKernelGGL((policy_head4_kernel<T, 2>), dim3((L.B + 3) / 4), dim3(256), lds, s, hd);
+        if ((e = hipGetLastError()) != hipSuccess) return e;
+    } else {
     a.in = x; a.w = layer(li); a.shift = shift(li); a.skip = nullptr; a.out = L.pmid; a.Ci = L.CP; a.Co = KH_POLICY_MID; ++li;
     if ((e = launch_conv<T, 1, 0>(a, s)) != hipSuccess) return e;
     a.in = L.pmid; a.w = layer(li); a.shift = shift(li); a.out = L.logits; a.Ci = KH_POLICY_MID; a.Co = 128; ++li;
     if ((e = launch_conv<T, 1, 2>(a, s)) != hipSuccess) return e;
+    launch_softmax4672(L.logits, L.policy, L.B, L.flags, s);                  // nn.cpp:80
+    }
     // value head, first half                                                nn.cpp:83-85
     int vb = (int)((npix + 255) / 256);
     if (vb > 4096) vb = 4096;
@@ -1258,6 +1512,10 @@ template <typename T> static hipError_t run(const LayersArgs& L, hipStream_t s)
 }  // namespace lay
 
 #ifdef KAMI_WIDE_DIAG
+extern "C" int kh_debug_t128_stamps(unsigned long long* out, int n)
+{
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(lay::g_t128_stamps), (size_t)n * 8, 0, hipMemcpyDeviceToHost);
+}
 extern "C" int kh_debug_wide_stamps(unsigned long long* out, int n)
 {
     return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(lay::g_wide_stamps), (size_t)n * 8, 0, hipMemcpyDeviceToHost);
