@@ -614,9 +614,8 @@ int forward_layers(kh_engine* e, const Weights& W, Slot& s, const float* d_in, i
     L.vw = W.ly_misc.as<float>(); L.vshift = W.ly_vshift;
     L.wh = W.ly_wh_ok ? W.ly_wh.as<unsigned short>() : nullptr;
     L.policy = d_policy; L.flags = flags; L.want_logits = d_logits_out != nullptr;
-    HIPCHK(kh::launch_layers(e->cfg.dtype, L, st));                                             // ... and the softmax, nn.cpp:80
-    const float* fcw = W.ly_misc.as<float>() + W.ly_CP;
-    kh::launch_value_fc(L.v64, fcw, fcw + (size_t)KH_VALUE_WIDTH * 64, d_vfull, B, flags, st);   // nn.cpp:86-88
+    L.fcw = W.ly_misc.as<float>() + W.ly_CP; L.fcb = L.fcw + (size_t)KH_VALUE_WIDTH * 64; L.vfull = d_vfull;
+    HIPCHK(kh::launch_layers(e->cfg.dtype, L, st));              // tower, policy head + softmax (nn.cpp:72-80), value head (nn.cpp:83-88)
     HIPCHK(hipGetLastError());
     return KH_OK;
 }

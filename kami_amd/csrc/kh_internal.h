@@ -86,6 +86,9 @@ struct LayersArgs {
     float* policy;                 // [B][4672]: launch_layers runs the softmax itself (nn.cpp:80)
     int* flags;                    // NaN flags ([0] policy, [1] value)
     bool want_logits;              // the caller asked for the pre-softmax logits in `logits`
+    const float* fcw;              // valuefc.weight [256][64], .bias [256] (device); launch_layers runs the value FC too
+    const float* fcb;
+    float* vfull;                  // [B][256]
 };
 size_t layers_lds_bytes(int Ci);
 // exact-fp32 MFMA convolution (conv_f32_kernel) for the trainer: out [B][64][Co] = conv(in [B][64][Ci]) + bias (nullable),

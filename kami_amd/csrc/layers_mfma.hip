@@ -800,8 +800,14 @@ struct Head4Args {
     const float* bias2;           // [128] policyconv2 bias, planes >= 73 zero
     float* policy;                // [B][4672]
     float* logits;                // nullable [B][4672]
-    int* flags;                   // [0]: a NaN in some policy row (nn.cpp:176-177)
+    int* flags;                   // [0]: a NaN in some policy row (nn.cpp:176-177); [1]: in the value tensor (nn.cpp:179-180)
     int B;
+    // value head (nn.cpp:83-88), nullable as a whole (vw == nullptr: the separate kernels run it)
+    const float* vw;              // [Ci] valueconv weight * vbatchnorm scale
+    float vshift;
+    const float* fcw;             // [256][64] valuefc.weight
+    const float* fcb;             // [256]
+    float* vfull;                 // [B][256]
 };
 
 __device__ __forceinline__ float wave_max_f(float v)
@@ -908,6 +914,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
         }
     };
+    float vsum[2] = { 0.0f, 0.0f };                         // valueconv partial sums of this lane's two pixels, its half of the channels
 #pragma unroll
     for (int pass = 0; pass < NP; ++pass) {
         if (pass > 0) __syncthreads();
@@ -916,6 +923,25 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         if (pass == 0) {
 #pragma unroll
             for (int f = 0; f < 8; ++f) A[0][f] = *reinterpret_cast<const V*>(smem + lane * 16 + f * 1024);
+        }
+        if (a.vw) {
+            // valueconv (C -> 1) on the staged board: lane (pixel, h) takes channels 64 h .. 64 h + 63 of this pass
+            const float* vw = a.vw + pass * Ci + 64 * h;
+#pragma unroll
+            for (int hp = 0; hp < 2; ++hp) {
+                const char* row = smem + LDS_IMG + wave * board_bytes + (32 * hp + lp) * stride + h * 128;
+#pragma unroll
+                for (int c8 = 0; c8 < 8; ++c8) {
+                    const u32x4 u = *reinterpret_cast<const u32x4*>(row + c8 * 16);
+                    const float4 w0 = *reinterpret_cast<const float4*>(vw + c8 * 8), w1 = *reinterpret_cast<const float4*>(vw + c8 * 8 + 4);
+                    float s = vsum[hp];
+                    s = fmaf(from_bits<T>((unsigned short)(u.x & 0xffff)), w0.x, s); s = fmaf(from_bits<T>((unsigned short)(u.x >> 16)), w0.y, s);
+                    s = fmaf(from_bits<T>((unsigned short)(u.y & 0xffff)), w0.z, s); s = fmaf(from_bits<T>((unsigned short)(u.y >> 16)), w0.w, s);
+                    s = fmaf(from_bits<T>((unsigned short)(u.z & 0xffff)), w1.x, s); s = fmaf(from_bits<T>((unsigned short)(u.z >> 16)), w1.y, s);
+                    s = fmaf(from_bits<T>((unsigned short)(u.w & 0xffff)), w1.z, s); s = fmaf(from_bits<T>((unsigned short)(u.w >> 16)), w1.w, s);
+                    vsum[hp] = s;
+                }
+            }
         }
         four_steps(pass * 4);
     }
@@ -976,6 +1002,32 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                     if (lo) lo[ch] = v;
                 }
             }
+    }
+    // ---- value head: vbatchnorm + ReLU on the 64 valueconv sums, Linear(64, 256), tanh (nn.cpp:84-88); this wave's board
+    if (a.vw) {
+        float* v64 = reinterpret_cast<float*>(smem + LDS_IMG + 4 * board_bytes) + wave * 64;
+#pragma unroll
+        for (int hp = 0; hp < 2; ++hp) {
+            // the two channel halves of a pixel sit in lanes l and l + 32
+            const unsigned u = __float_as_uint(vsum[hp]);
+            const auto sw = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+            const float tot = __uint_as_float(sw[0]) + __uint_as_float(sw[1]);
+            if (h == 0) v64[32 * hp + lp] = relu_keep_nan(tot + a.vshift);
+        }
+        // (same wave wrote it: its LDS operations are ordered)
+        float o[4] = { a.fcb[lane * 4], a.fcb[lane * 4 + 1], a.fcb[lane * 4 + 2], a.fcb[lane * 4 + 3] };
+#pragma unroll 4
+        for (int k4 = 0; k4 < 16; ++k4) {
+            const float4 hv = *reinterpret_cast<const float4*>(v64 + k4 * 4);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float4 wv = *reinterpret_cast<const float4*>(a.fcw + (size_t)(lane * 4 + j) * 64 + k4 * 4);
+                o[j] = fmaf(hv.x, wv.x, o[j]); o[j] = fmaf(hv.y, wv.y, o[j]); o[j] = fmaf(hv.z, wv.z, o[j]); o[j] = fmaf(hv.w, wv.w, o[j]);
+            }
+        }
+        float4 r = make_float4(tanhf(o[0]), tanhf(o[1]), tanhf(o[2]), tanhf(o[3]));
+        *reinterpret_cast<float4*>(a.vfull + (size_t)b * KH_VALUE_WIDTH + lane * 4) = r;
+        if (r.x != r.x || r.y != r.y || r.z != r.z || r.w != r.w) atomicOr(&a.flags[1], 1);
     }
 }
 
@@ -1359,6 +1411,7 @@ static hipError_t run_f32(const LayersArgs& L, hipStream_t s)
     int vb = (int)((npix + 255) / 256);
     if (vb > 4096) vb = 4096;
     hipLaunchKernelGGL(value_conv_f32_kernel, dim3(vb), dim3(256), 0, s, x, L.vw, L.vshift, L.v64, npix, L.CP);
+    launch_value_fc(L.v64, L.fcw, L.fcb, L.vfull, L.B, L.flags, s);           // nn.cpp:86-88
     return hipGetLastError();
 }
 
@@ -1484,8 +1537,9 @@ template <typename T> static hipError_t run(const LayersArgs& L, hipStream_t s)
         Head4Args hd;
         hd.x = x; hd.w = L.wh; hd.shift1 = shift(li); hd.bias2 = shift(li + 1); hd.policy = L.policy; hd.logits = L.want_logits ? L.logits : nullptr;
         hd.flags = L.flags; hd.B = L.B;
+        hd.vw = L.vw; hd.vshift = L.vshift; hd.fcw = L.fcw; hd.fcb = L.fcb; hd.vfull = L.vfull;
         li += 2;
-        const int lds = 4 * CHUNKB + 4 * 64 * (128 * 2 + 16);
+        const int lds = 4 * CHUNKB + 4 * 64 * (128 * 2 + 16) + 4 * 64 * 4;
         static std::atomic<bool> attr_done{ false };
         if (!attr_done.load(std::memory_order_acquire)) {
             if ((e = hipFuncSetAttribute(reinterpret_cast<const void*>(&policy_head4_kernel<T, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)) != hipSuccess) return e;
@@ -1501,11 +1555,12 @@ template <typename T> static hipError_t run(const LayersArgs& L, hipStream_t s)
     a.in = L.pmid; a.w = layer(li); a.shift = shift(li); a.out = L.logits; a.Ci = KH_POLICY_MID; a.Co = 128; ++li;
     if ((e = launch_conv<T, 1, 2>(a, s)) != hipSuccess) return e;
     launch_softmax4672(L.logits, L.policy, L.B, L.flags, s);                  // nn.cpp:80
-    }
-    // value head, first half                                                nn.cpp:83-85
+    // value head                                                            nn.cpp:83-88
     int vb = (int)((npix + 255) / 256);
     if (vb > 4096) vb = 4096;
     hipLaunchKernelGGL(value_conv_kernel<T>, dim3(vb), dim3(256), 0, s, x, L.vw, L.vshift, L.v64, npix, L.CP);
+    launch_value_fc(L.v64, L.fcw, L.fcb, L.vfull, L.B, L.flags, s);
+    }
     return hipGetLastError();
 }
 
