@@ -28,6 +28,7 @@ using f16x8 = __attribute__((ext_vector_type(8))) _Float16;
 using f32x16 = __attribute__((ext_vector_type(16))) float;
 using u32x4 = __attribute__((ext_vector_type(4))) unsigned;
 using u32x2 = __attribute__((ext_vector_type(2))) unsigned;
+using f32x4s = __attribute__((ext_vector_type(4))) float;
 
 constexpr int PITCH = 12;
 constexpr int NPIX = 10 * PITCH;
@@ -984,25 +985,36 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     sum = wave_sum_f(sum);
     const float ls = logf(sum);
     const bool row_nan = __any(nan);                        // any NaN logit poisons the whole row in the reference
-    if (b >= a.B) return;
-    if (row_nan && lane == 0) atomicOr(&a.flags[0], 1);
+    // The lane layout (4 consecutive planes of one pixel per lane, pixels 292 bytes apart) makes a direct store 64
+    // scattered 4-byte writes per instruction.  The row goes through LDS instead (ring and images are dead: one barrier
+    // so that no wave is still reading them): [pixel][73] fp32 = the row's own memory order, then 16-byte coalesced
+    // non-temporal stores of the wave's 18 688 contiguous bytes.
+    __syncthreads();
+    float* rowbuf = reinterpret_cast<float*>(smem) + wave * KH_PSIZE;
+    const bool live = b < a.B;
+    auto put_row = [&](float* dst_row, bool probs) {
 #pragma unroll
-    for (int hp = 0; hp < 2; ++hp) {
-        const int pix = 32 * hp + lp;
-        float* po = a.policy + (size_t)b * KH_PSIZE + pix * KH_POLICY_PLANES;
-        float* lo = a.logits ? a.logits + (size_t)b * KH_PSIZE + pix * KH_POLICY_PLANES : nullptr;
+        for (int hp = 0; hp < 2; ++hp)
 #pragma unroll
-        for (int ms = 0; ms < 3; ++ms)                      // planes 96..127 are padding
+            for (int ms = 0; ms < 3; ++ms)                  // planes 96..127 are padding
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int ch = ms * 32 + 8 * (r >> 2) + 4 * h + (r & 3);
-                if (ch < KH_POLICY_PLANES) {
-                    const float v = acc[ms * 2 + hp][r];
-                    po[ch] = row_nan ? NAN : expf((v - m) - ls);
-                    if (lo) lo[ch] = v;
+                for (int r = 0; r < 16; ++r) {
+                    const int ch = ms * 32 + 8 * (r >> 2) + 4 * h + (r & 3);
+                    if (ch < KH_POLICY_PLANES) {
+                        const float v = acc[ms * 2 + hp][r];
+                        rowbuf[(32 * hp + lp) * KH_POLICY_PLANES + ch] = probs ? (row_nan ? NAN : expf((v - m) - ls)) : v;
+                    }
                 }
-            }
-    }
+        // (same wave wrote it: its LDS operations are ordered)
+        if (live) {
+            for (int i = lane; i < KH_PSIZE / 4; i += 64)
+                __builtin_nontemporal_store(*reinterpret_cast<const f32x4s*>(rowbuf + 4 * i), reinterpret_cast<f32x4s*>(dst_row) + i);
+        }
+    };
+    if (a.logits) put_row(a.logits + (size_t)(live ? b : 0) * KH_PSIZE, false);
+    put_row(a.policy + (size_t)(live ? b : 0) * KH_PSIZE, true);
+    if (!live) return;
+    if (row_nan && lane == 0) atomicOr(&a.flags[0], 1);
     // ---- value head: vbatchnorm + ReLU on the 64 valueconv sums, Linear(64, 256), tanh (nn.cpp:84-88); this wave's board
     if (a.vw) {
         float* v64 = reinterpret_cast<float*>(smem + LDS_IMG + 4 * board_bytes) + wave * 64;

@@ -123,7 +123,8 @@ for Cc, Rr, B, dt in ((128, 10, 1024, "bf16"), (256, 20, 256, "f16"), (256, 20, 
     for d in (f"pmcf_{wtag}", f"pmcw_{wtag}", f"pmcs_{wtag}"):
         ctr.update(counters(d, key))
     calls = {r["Name"]: int(r["Calls"]) for r in rows}
-    fwd = min(int(r["Calls"]) for r in rows if "softmax" in r["Name"]) if any("softmax" in r["Name"] for r in rows) else 1
+    once = [int(r["Calls"]) for r in rows if "policy_head4" in r["Name"] or "softmax" in r["Name"] or "tower128" in r["Name"]]
+    fwd = min(once) if once else 1                         # kernels that run once per forward
     per_forward_ns = sum(float(r["TotalDurationNs"]) for r in rows if "fillBuffer" not in r["Name"] and "copyBuffer" not in r["Name"]) / fwd
     flops = (1152 * 119 * Cc + 2304 * Rr * Cc * Cc + 16512 * Cc + 1228800) * B
     entry = {"workload": f"{B} x (119x8x8) planes, {Rr}-block x {Cc}-filter net, {dt} (tools/wide_profile.py {Cc} {Rr} {B} {dt})",
