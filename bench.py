@@ -256,6 +256,20 @@ def end_to_end_legs(NN, W, L, device):
                                                     "(the legacy float ABI of NN::infer, nn.cpp:155-187)",
                     "threads": T, "value": round(threaded(make_infer, B, T), 1), "unit": "leaf-evals/s",
                     "pcie_bound": "2.07 M/s at 63 GB/s per direction (30 464 B in, 18 692 B out per evaluation; SURVEY 7)"})
+    pinned = []
+
+    def make_infer_pinned(i):
+        x = np.random.default_rng(i).random((B, 8, 8, F), dtype=np.float32)
+        pol = np.empty((B, 4672), np.float32); val = np.empty(B, np.float32)
+        nn.pin(x); nn.pin(pol); pinned.extend([x, pol])
+        return lambda: nn.infer(x, B, pol, val)
+    for T in (1, 2, 4):
+        out.append({"call": "kh_infer, caller buffers registered once with kh_pin_buffer", "workload": "as above; plain DMA out of / into the caller's pages, "
+                    "four chunks of the batch alternating between two streams", "threads": T,
+                    "value": round(threaded(make_infer_pinned, B, T), 1), "unit": "leaf-evals/s"})
+        for arr in pinned:
+            nn.unpin(arr)
+        pinned.clear()
     del nn
     F = 30
     nn = NN(8, 8, F, 4672, filters=64, residuals=6, dtype="bf16", device=device, value_mode=L.KH_VALUE_PER_SAMPLE0)

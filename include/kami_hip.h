@@ -148,6 +148,16 @@ int  kh_clone(kh_engine* src, kh_engine** out);
  * Returns KH_ERR_NAN_POLICY / KH_ERR_NAN_VALUE where the reference throws. */
 int  kh_infer(kh_engine* e, const float* input, int batch, float* policy, float* value);
 
+/* Optional, for kh_infer's host buffers: register a LONG-LIVED caller buffer (selfplay.cpp's `batch` / `inf_policy`
+ * arrays live as long as their inference thread) with the device, so that kh_infer moves it by plain DMA instead of having
+ * the runtime pin and unpin the caller's pages at every call, and overlaps the upload of one part of the batch with the
+ * kernel and the policy download of the previous part.  Applies when BOTH `input` and `policy` of a call lie inside
+ * registered buffers (bf16 / f16 engines of <= 64 filters); results are the same bits either way.  The caller must
+ * kh_unpin_buffer before it frees the memory: a registration that outlives its allocation would let the device read
+ * whatever is mapped there next — which is why this is opt-in and not something kh_infer does behind the caller's back. */
+int  kh_pin_buffer(kh_engine* e, void* ptr, size_t bytes);
+int  kh_unpin_buffer(kh_engine* e, void* ptr);
+
 /* Diagnostic superset of kh_infer used by the parity tests: additionally returns
  * the whole value tensor [batch][256] (nn.cpp:86-88) and, if non-NULL, the
  * pre-softmax policy logits [batch][4672] (nn.cpp:75-79). */

@@ -49,6 +49,8 @@ SYMBOLS = {
     "kh_generation": (C.c_int, [_P]),
     "kh_clone": (C.c_int, [_P, C.POINTER(_P)]),
     "kh_infer": (C.c_int, [_P, _P, C.c_int, _P, _P]),
+    "kh_pin_buffer": (C.c_int, [_P, _P, C.c_size_t]),
+    "kh_unpin_buffer": (C.c_int, [_P, _P]),
     "kh_infer_full": (C.c_int, [_P, _P, C.c_int, _P, _P, _P]),
     "kh_encode": (C.c_int, [_P, _P, C.c_int, _P]),
     "kh_encode_infer": (C.c_int, [_P, _P, C.c_int, _P, _P]),

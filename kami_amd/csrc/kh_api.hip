@@ -443,6 +443,7 @@ struct Slot {
     DevMem in, x, t, u, ph, logits, policy, v64, vfull, flags, boards, planes, offs, acts, priors, actin;
     DevMem pack_in, pack_out;    // legal-move host path: arguments / results packed for one copy each way
     PinMem hin, hout;
+    hipStream_t stream2 = nullptr;   // registered caller buffers: chunks alternate between the two streams
     bool busy = false;
     bool flags_clean = false;    // device NaN flags known to be zero
     // device-pointer API: the scratch above is shared by every caller stream, so a call on another stream
@@ -471,6 +472,9 @@ struct kh_engine {
     std::mutex co_mu;
     std::atomic<int> small_calls{ 0 };       // synchronous small-batch calls currently inside the engine
     std::atomic<int> co_target{ 0 }, co_wait_us{ 0 };
+    // caller buffers registered with kh_pin_buffer: [base, base + bytes)
+    std::mutex pin_mu;
+    std::vector<std::pair<const char*, size_t>> pinned;
 };
 
 namespace {
@@ -661,6 +665,61 @@ bool fused_ingest(const kh_engine* e, const Weights& W)
 
 struct LegalIO { const int32_t* offsets; const int32_t* actions; float* priors; };
 
+bool is_pinned(kh_engine* e, const void* p, size_t bytes)
+{
+    std::lock_guard<std::mutex> lk(e->pin_mu);
+    const char* c = static_cast<const char*>(p);
+    for (auto& r : e->pinned)
+        if (c >= r.first && c + bytes <= r.first + r.second) return true;
+    return false;
+}
+
+// kh_infer with REGISTERED caller buffers (kh_pin_buffer) on the whole-network kernel: the copies are plain DMA out of /
+// into the caller's pages, so the call is cut into four chunks that alternate between two streams — chunk k + 1's upload
+// runs under chunk k's kernel and policy download.  PCIe is what bounds this ABI (30 464 B in, 18 692 B out per
+// evaluation at 119 planes); pageable buffers cost the runtime a pin / unpin of the caller's pages per call on top.
+int infer_host_pinned(kh_engine* e, const Weights& W, Slot& s, const float* input, int batch, float* policy, float* value)
+{
+    const size_t F = e->cfg.features;
+    if (!s.stream2) HIPCHK(hipStreamCreateWithFlags(&s.stream2, hipStreamNonBlocking));
+    hipStream_t st[2] = { s.stream, s.stream2 };
+    int* flags = s.flags.as<int>();
+    if (!s.flags_clean) {
+        HIPCHK(hipMemsetAsync(flags, 0, 16, st[0]));
+        HIPCHK(hipStreamSynchronize(st[0]));
+        s.flags_clean = true;
+    }
+    const int NCK = batch >= 256 ? 4 : (batch >= 64 ? 2 : 1);
+    const int per = ((batch + NCK - 1) / NCK + 1) & ~1;            // whole board pairs per chunk
+    float* d_in = s.in.as<float>();
+    float* d_pol = s.policy.as<float>();
+    float* d_vf = s.vfull.as<float>();
+    for (int k = 0, lo = 0; lo < batch; ++k, lo += per) {
+        const int n = std::min(per, batch - lo);
+        hipStream_t q = st[k & 1];
+        HIPCHK(hipMemcpyAsync(d_in + (size_t)lo * 64 * F, input + (size_t)lo * 64 * F, (size_t)n * 64 * F * 4, hipMemcpyHostToDevice, q));
+        kh::TowerArgs a;
+        a.in = d_in + (size_t)lo * 64 * F; a.boards = nullptr; a.B = n; a.F = e->cfg.features; a.R = e->cfg.residuals;
+        a.wstream = W.tw_stream.as<char>(); a.nchunks = W.tw_nchunks;
+        a.params = W.tw_par.as<float>(); a.npar = W.tw_npar;
+        a.fcw4 = W.tw_fc4.as<float>(); a.fcb = W.tw_fc4.as<float>() + (size_t)KH_VALUE_WIDTH * 64;
+        a.policy = d_pol + (size_t)lo * KH_PSIZE; a.vfull = d_vf + (size_t)lo * KH_VALUE_WIDTH; a.logits = nullptr; a.flags = flags;
+        HIPCHK(kh::launch_tower(e->cfg.dtype, W.tw_FP, a, e->num_cus, q));
+        HIPCHK(hipMemcpyAsync(policy + (size_t)lo * KH_PSIZE, d_pol + (size_t)lo * KH_PSIZE, (size_t)n * KH_PSIZE * 4, hipMemcpyDeviceToHost, q));
+    }
+    HIPCHK(hipStreamSynchronize(st[1]));
+    // value (nn.cpp:186: the first `batch` floats of the flattened [batch,256] tensor, or column 0) and the NaN flags
+    if (e->cfg.value_mode == KH_VALUE_REFERENCE_FLAT) HIPCHK(hipMemcpyAsync(value, d_vf, (size_t)batch * 4, hipMemcpyDeviceToHost, st[0]));
+    else HIPCHK(hipMemcpy2DAsync(value, 4, d_vf, KH_VALUE_WIDTH * 4, 4, batch, hipMemcpyDeviceToHost, st[0]));
+    int fl[4] = { 0, 0, 0, 0 };
+    HIPCHK(hipMemcpyAsync(fl, flags, 16, hipMemcpyDeviceToHost, st[0]));
+    HIPCHK(hipStreamSynchronize(st[0]));
+    if (fl[0] | fl[1]) s.flags_clean = false;
+    if (fl[0]) return fail(KH_ERR_NAN_POLICY, "inference policy output contains NaN");   // nn.cpp:176-177
+    if (fl[1]) return fail(KH_ERR_NAN_VALUE, "inference value output contains NaN");     // nn.cpp:179-180
+    return KH_OK;
+}
+
 int infer_host(kh_engine* e, const float* input, const kh_board* boards, int batch,
                float* policy, float* value, float* value_full, float* logits, const LegalIO* legal = nullptr)
 {
@@ -684,6 +743,9 @@ int infer_host(kh_engine* e, const float* input, const kh_board* boards, int bat
     if ((rc = slot_ensure(e, s, batch, true))) return rc;
     const size_t B = batch, F = e->cfg.features;
     hipStream_t st = s.stream;
+    if (input && policy && value && !legal && !logits && !value_full && e->cfg.dtype != KH_F32 && W->tw_ok &&
+        (reinterpret_cast<uintptr_t>(input) & 15) == 0 && is_pinned(e, input, B * 64 * F * 4) && is_pinned(e, policy, B * KH_PSIZE * 4))
+        return infer_host_pinned(e, *W, s, input, batch, policy, value);
     const float* d_in;
     const bool fused = boards && fused_ingest(e, *W) && !logits;
     // The search's call (records or planes in, legal priors + one value per position out): everything
@@ -1186,10 +1248,12 @@ void kh_destroy(kh_engine* e)
     (void)hipSetDevice(e->cfg.device);
     auto kill = [](Slot* s) {
         if (s && s->stream) { (void)hipStreamSynchronize(s->stream); (void)hipStreamDestroy(s->stream); }
+        if (s && s->stream2) { (void)hipStreamSynchronize(s->stream2); (void)hipStreamDestroy(s->stream2); }
         if (s && s->scratch_done) (void)hipEventDestroy(s->scratch_done);
     };
     for (auto& s : e->slots) kill(s.get());
     kill(e->devslot.get());
+    for (auto& r : e->pinned) (void)hipHostUnregister(const_cast<char*>(r.first));
     delete e;
 }
 
@@ -1675,6 +1739,32 @@ int kh_time_encode_device(kh_engine* e, const kh_board* d_boards, int batch, flo
     EncCtx c{ e, d_boards, batch, d_planes };
     return time_loop(e, iters, ms_per_launch,
                      [](void* p) { auto* c = static_cast<EncCtx*>(p); return kh_encode_device(c->e, c->b, c->B, c->planes, nullptr); }, &c);
+}
+
+int kh_pin_buffer(kh_engine* e, void* ptr, size_t bytes)
+{
+    if (!e || !ptr || !bytes) return fail(KH_ERR_INVALID, "null argument");
+    int rc = set_device(e);
+    if (rc) return rc;
+    HIPCHK(hipHostRegister(ptr, bytes, hipHostRegisterDefault));
+    std::lock_guard<std::mutex> lk(e->pin_mu);
+    e->pinned.emplace_back(static_cast<const char*>(ptr), bytes);
+    return KH_OK;
+}
+
+int kh_unpin_buffer(kh_engine* e, void* ptr)
+{
+    if (!e || !ptr) return fail(KH_ERR_INVALID, "null argument");
+    {
+        std::lock_guard<std::mutex> lk(e->pin_mu);
+        auto it = std::find_if(e->pinned.begin(), e->pinned.end(), [&](const std::pair<const char*, size_t>& r) { return r.first == ptr; });
+        if (it == e->pinned.end()) return fail(KH_ERR_INVALID, "buffer was not registered with kh_pin_buffer");
+        e->pinned.erase(it);
+    }
+    int rc = set_device(e);
+    if (rc) return rc;
+    HIPCHK(hipHostUnregister(ptr));
+    return KH_OK;
 }
 
 int kh_dev_alloc(kh_engine* e, size_t bytes, void** d_ptr)

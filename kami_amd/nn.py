@@ -238,6 +238,13 @@ class NN:
         _chk(self._lib.kh_submit_encode_infer_legal(self._h, _ptr(b), n, _ptr(offs), _ptr(acts), _ptr(priors), _ptr(value), C.byref(t)))
         return Ticket(self, t.value, (priors[:int(offs[-1])], value), (b, offs, acts, priors))
 
+    def pin(self, array: np.ndarray) -> None:
+        """kh_pin_buffer: register a long-lived numpy buffer used as infer()'s input / policy (unpin before freeing it)."""
+        _chk(self._lib.kh_pin_buffer(self._h, _ptr(array), array.nbytes))
+
+    def unpin(self, array: np.ndarray) -> None:
+        _chk(self._lib.kh_unpin_buffer(self._h, _ptr(array)))
+
     def set_coalesce(self, target_batch: int = 0, max_wait_us: int = 0) -> None:
         _chk(self._lib.kh_set_coalesce(self._h, target_batch, max_wait_us))
 

@@ -629,6 +629,39 @@ def test_selfplay_pool_pipelined_through_the_queue():
         assert 0 < r.nact <= S.MAX_RECORD_ACTIONS and abs(v.sum() - 1.0) < 1e-3
 
 
+@pytest.mark.parametrize("mode", [L.KH_VALUE_REFERENCE_FLAT, L.KH_VALUE_PER_SAMPLE0])
+def test_registered_caller_buffers_give_the_same_bits(mode):
+    """kh_pin_buffer: kh_infer with registered input / policy buffers takes the chunked two-stream path (plain DMA out
+    of the caller's pages, upload of one part under the kernel and download of the previous one).  Same bits as the
+    pageable path at every batch size — odd ones, ones below the chunking thresholds, 300 (second row of the reference's
+    flat value copy-out) — and the NaN contract holds; an unregistered pointer cannot be unpinned."""
+    F, C, R = 119, 64, 2
+    nn = NN(8, 8, F, 4672, filters=C, residuals=R, dtype="bf16", value_mode=mode)
+    nn.load_weights(W.random_weights(F, C, R, seed=6, peaky=10.0), 1)
+    xin = np.zeros((600, 8, 8, F), np.float32)
+    pol = np.zeros((600, 4672), np.float32)
+    nn.pin(xin); nn.pin(pol)
+    try:
+        rng = np.random.default_rng(3)
+        for B in (1, 2, 63, 64, 255, 300, 512, 599):
+            x = rng.random((B, 8, 8, F), dtype=np.float32)
+            want_p, want_v = nn.infer(x)                                     # pageable buffers
+            xin[:B] = x
+            val = np.empty(B, np.float32)
+            got_p, got_v = nn.infer(xin[:B], B, pol[:B], val)                # registered buffers
+            assert got_p is not want_p and np.array_equal(got_p, want_p) and np.array_equal(got_v, want_v)
+        xin[5, 3, 3, 7] = np.nan
+        with pytest.raises(KamiError) as ei:
+            nn.infer(xin[:64], 64, pol[:64], np.empty(64, np.float32))
+        assert ei.value.status == L.KH_ERR_NAN_POLICY
+        xin[5, 3, 3, 7] = 0.5
+        nn.infer(xin[:64], 64, pol[:64], np.empty(64, np.float32))            # and the flags are clean again
+    finally:
+        nn.unpin(xin); nn.unpin(pol)
+    with pytest.raises(KamiError):
+        nn.unpin(xin)
+
+
 def test_bench_two_ranks_control_flow(tmp_path):
     """bench.py under torch.distributed.run with 2 ranks (sharing this box's single GPU over gloo:
     RCCL refuses duplicate devices): barrier, max-over-ranks and the whole-job aggregate."""
