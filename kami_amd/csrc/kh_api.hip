@@ -200,13 +200,10 @@ void pack_layer(std::vector<uint16_t>& out, int dtype, const float* w, const flo
 // output channels, [Co/64][Ci/64][tap][4][2][lane][8] — 64-channel slices of the reduction outermost, so that
 // the kernel's variants (whole image staged at once, or in passes of 64 / 128 channels) all walk the same
 // order and agree bit for bit.
-void pack_layer_generic(std::vector<uint16_t>& out, int dtype, const float* w, const float* scale,
+void pack_layer_generic(uint16_t* o, int dtype, const float* w, const float* scale,
                         int Co, int Ci, int taps, int CoP, int CiP)
 {
-    // (runs at every weight install, the trainer's included: sized once, written by index)
-    const size_t base = out.size();
-    out.resize(base + (size_t)CoP * CiP * taps);
-    uint16_t* o = out.data() + base;
+    // (runs at every weight install, the trainer's included: written by index into a slice sized CoP * CiP * taps)
     const bool bf = dtype == KH_BF16;
     for (int cb = 0; cb < CoP / 64; ++cb)
         for (int slice = 0; slice < CiP / 64; ++slice)
@@ -228,12 +225,9 @@ void pack_layer_generic(std::vector<uint16_t>& out, int dtype, const float* w, c
 // The same fragments for conv4_mfma_kernel (four boards x 128 output channels per workgroup): 8 KB chunks of 32 input
 // channels x 128 output channels, [Co/128][Ci/64][tap][half][ks2][ms 0..3][lane][8] — the reduction walks in the same
 // order as above (64-channel slices, then taps, then k-steps), so both kernels produce the same bits.
-void pack_layer_wide128(std::vector<uint16_t>& out, int dtype, const float* w, const float* scale,
+void pack_layer_wide128(uint16_t* o, int dtype, const float* w, const float* scale,
                         int Co, int Ci, int taps, int CoP, int CiP)
 {
-    const size_t base = out.size();
-    out.resize(base + (size_t)CoP * CiP * taps);
-    uint16_t* o = out.data() + base;
     const bool bf = dtype == KH_BF16;
     for (int cb = 0; cb < CoP / 128; ++cb)
         for (int slice = 0; slice < CiP / 64; ++slice)
@@ -254,7 +248,7 @@ void pack_layer_wide128(std::vector<uint16_t>& out, int dtype, const float* w, c
 
 // fp32 fragments for conv_f32_kernel: [Co/64][Ci slices of <= 128][tap][slice/8][2][lane][4]; lane (r, h) holds
 // W[co = ms*32 + r][ci = 8j + 4h + 0..3]  (one slice up to 128 input channels: the image of a slice is what fits LDS)
-void pack_layer_f32(std::vector<float>& out, const float* w, const float* scale, int Co, int Ci, int taps, int CoP, int CiP)
+void pack_layer_f32(float* o, const float* w, const float* scale, int Co, int Ci, int taps, int CoP, int CiP)
 {
     for (int cb = 0; cb < CoP / 64; ++cb)
       for (int c_lo = 0; c_lo < CiP; c_lo += 128)
@@ -265,7 +259,7 @@ void pack_layer_f32(std::vector<float>& out, const float* w, const float* scale,
                         const int r = l & 31, h = l >> 5;
                         for (int i = 0; i < 4; ++i) {
                             const int co = cb * 64 + ms * 32 + r, ci = j * 8 + 4 * h + i;
-                            out.push_back((co < Co && ci < Ci) ? w[((size_t)co * Ci + ci) * taps + tap] * (scale ? scale[co] : 1.0f) : 0.0f);
+                            *o++ = (co < Co && ci < Ci) ? w[((size_t)co * Ci + ci) * taps + tap] * (scale ? scale[co] : 1.0f) : 0.0f;
                         }
                     }
 }
@@ -277,22 +271,27 @@ int build_layers(Weights& W, const HostNet& n, int dtype, int F, int C, int R)
     const int FP = f32 ? (F + 7) / 8 * 8 : (F + 63) / 64 * 64, CP = (C + 63) / 64 * 64;
     // LDS image of two boards: 2 x 120 x (Ci * elem + 16) bytes must fit 160 KB
     if (CP > 256 || FP > 256) return KH_OK;      // not covered: ly_ok stays false
-    std::vector<uint16_t> w, w4;
+    // Every layer's fragments are packed by its own job into its own slice: the jobs run on a few host threads (this is
+    // on the trainer's path too — kh_train installs its result here — and a 20x256 net is 48 M fragments' worth).
+    std::vector<uint16_t> w, w4, wh;
     std::vector<float> wf;
     std::vector<float> shift;
+    struct Job { int kind; size_t off; const float* wt; std::vector<float> sc; int Co, Ci, taps, CoP, CiP; };   // kind 0 generic, 1 wide128, 2 f32, 3 head
+    std::vector<Job> jobs;
+    size_t nw = 0, nw4 = 0, nwf = 0, nwh = 0;
     std::vector<float> sc(256), sh(256);
     auto add = [&](const float* wt, const ConvBN* bn, const float* bias, int Co, int Ci, int taps, int CoP, int CiP) {
-        W.ly_w_off.push_back(w.size());
         W.ly_shift_off.push_back(shift.size());
         W.ly_w4_off.push_back((size_t)-1);
         if (bn) fold_bn(*bn, Co, sc.data(), sh.data());
         else for (int i = 0; i < Co; ++i) { sc[i] = 1.0f; sh[i] = bias[i]; }
-        if (f32) { W.ly_w_off.back() = wf.size(); pack_layer_f32(wf, wt, sc.data(), Co, Ci, taps, CoP, CiP); }
+        const std::vector<float> scv(sc.begin(), sc.begin() + Co);
+        const size_t n = (size_t)CoP * CiP * taps;
+        if (f32) { W.ly_w_off.push_back(nwf); jobs.push_back({ 2, nwf, wt, scv, Co, Ci, taps, CoP, CiP }); nwf += n; }
         else {
-            pack_layer_generic(w, dtype, wt, sc.data(), Co, Ci, taps, CoP, CiP);
+            W.ly_w_off.push_back(nw); jobs.push_back({ 0, nw, wt, scv, Co, Ci, taps, CoP, CiP }); nw += n;
             if (taps == 9 && CoP % 128 == 0 && (CiP == 128 || CiP == 256)) {     // conv4_mfma_kernel's shapes
-                W.ly_w4_off.back() = w4.size();
-                pack_layer_wide128(w4, dtype, wt, sc.data(), Co, Ci, taps, CoP, CiP);
+                W.ly_w4_off.back() = nw4; jobs.push_back({ 1, nw4, wt, scv, Co, Ci, taps, CoP, CiP }); nw4 += n;
             }
         }
         for (int i = 0; i < CoP; ++i) shift.push_back(i < Co ? sh[i] : 0.0f);
@@ -301,11 +300,31 @@ int build_layers(Weights& W, const HostNet& n, int dtype, int F, int C, int R)
     for (int i = 0; i < 2 * R; ++i) add(n.res[i].w, &n.res[i], nullptr, C, C, 9, CP, CP);
     add(n.pconv.w, &n.pconv, nullptr, KH_POLICY_MID, C, 1, KH_POLICY_MID, CP);
     add(n.p2w, nullptr, n.p2b, KH_POLICY_PLANES, KH_POLICY_MID, 1, 128, KH_POLICY_MID);
-    std::vector<uint16_t> wh;
-    if (!f32 && (CP == 128 || CP == 256)) {          // policy_head4_kernel's shapes
+    if (!f32 && (CP == 128 || CP == 256)) {          // policy_head4_kernel's shapes: policyconv then policyconv2
         fold_bn(n.pconv, KH_POLICY_MID, sc.data(), sh.data());
-        pack_layer_wide128(wh, dtype, n.pconv.w, sc.data(), KH_POLICY_MID, C, 1, KH_POLICY_MID, CP);
-        pack_layer_wide128(wh, dtype, n.p2w, nullptr, KH_POLICY_PLANES, KH_POLICY_MID, 1, 128, KH_POLICY_MID);
+        jobs.push_back({ 3, nwh, n.pconv.w, std::vector<float>(sc.begin(), sc.begin() + KH_POLICY_MID), KH_POLICY_MID, C, 1, KH_POLICY_MID, CP });
+        nwh += (size_t)KH_POLICY_MID * CP;
+        jobs.push_back({ 3, nwh, n.p2w, std::vector<float>(), KH_POLICY_PLANES, KH_POLICY_MID, 1, 128, KH_POLICY_MID });
+        nwh += (size_t)128 * KH_POLICY_MID;
+    }
+    w.resize(nw); w4.resize(nw4); wf.resize(nwf); wh.resize(nwh);
+    {
+        std::atomic<size_t> next{ 0 };
+        auto run = [&]() {
+            for (size_t j; (j = next.fetch_add(1)) < jobs.size();) {
+                const Job& jb = jobs[j];
+                const float* scp = jb.sc.empty() ? nullptr : jb.sc.data();
+                if (jb.kind == 0) pack_layer_generic(w.data() + jb.off, dtype, jb.wt, scp, jb.Co, jb.Ci, jb.taps, jb.CoP, jb.CiP);
+                else if (jb.kind == 1) pack_layer_wide128(w4.data() + jb.off, dtype, jb.wt, scp, jb.Co, jb.Ci, jb.taps, jb.CoP, jb.CiP);
+                else if (jb.kind == 2) pack_layer_f32(wf.data() + jb.off, jb.wt, scp, jb.Co, jb.Ci, jb.taps, jb.CoP, jb.CiP);
+                else pack_layer_wide128(wh.data() + jb.off, dtype, jb.wt, scp, jb.Co, jb.Ci, jb.taps, jb.CoP, jb.CiP);
+            }
+        };
+        const int nt = (int)std::min<size_t>(8, jobs.size());
+        std::vector<std::thread> th;
+        for (int t = 1; t < nt; ++t) th.emplace_back(run);
+        run();
+        for (auto& t : th) t.join();
     }
     std::vector<float> misc((size_t)CP + KH_VALUE_WIDTH * 64 + KH_VALUE_WIDTH, 0.0f);
     float vs, vsh;
@@ -455,6 +474,28 @@ struct Slot {
 
 struct Coalescer;       // the submit / wait queue, below
 
+struct TrainCache {
+    DevMem params, grads, work, dx, dp, dv, dloss;
+    PinMem pin;
+    hipStream_t st = nullptr;
+    hipGraph_t g = nullptr;
+    hipGraphExec_t x = nullptr;
+    int B = 0;
+    float lr = 0.0f;
+    bool valu = false, graph_tried = false;
+    void drop_graph()
+    {
+        if (x) (void)hipGraphExecDestroy(x);
+        if (g) (void)hipGraphDestroy(g);
+        x = nullptr; g = nullptr; graph_tried = false;
+    }
+    ~TrainCache()
+    {
+        drop_graph();
+        if (st) (void)hipStreamDestroy(st);
+    }
+};
+
 }  // namespace
 
 struct kh_engine {
@@ -472,6 +513,11 @@ struct kh_engine {
     std::mutex co_mu;
     std::atomic<int> small_calls{ 0 };       // synchronous small-batch calls currently inside the engine
     std::atomic<int> co_target{ 0 }, co_wait_us{ 0 };
+    // kh_train's workspace, staging, stream and recorded step: kept from call to call (selfplay.cpp:266 trains again and
+    // again with the same batch size and learning rate; allocating 0.1-2 GB and instantiating a ~270-node graph per
+    // call cost more than a dozen SGD steps)
+    std::mutex train_mu;
+    TrainCache* train = nullptr;
     // caller buffers registered with kh_pin_buffer: [base, base + bytes)
     std::mutex pin_mu;
     std::vector<std::pair<const char*, size_t>> pinned;
@@ -1254,6 +1300,7 @@ void kh_destroy(kh_engine* e)
     for (auto& s : e->slots) kill(s.get());
     kill(e->devslot.get());
     for (auto& r : e->pinned) (void)hipHostUnregister(const_cast<char*>(r.first));
+    delete e->train;
     delete e;
 }
 
@@ -1294,14 +1341,23 @@ int kh_train(kh_engine* e, const float* inputs, const float* obs_p, const float*
     const int F = e->cfg.features, C = e->cfg.filters, R = e->cfg.residuals, B = cfg->batch;
     std::unique_ptr<kh::TrainNet, void (*)(kh::TrainNet*)> net(kh::train_layout_new(F, C, R), kh::train_layout_free);
     const size_t nfl = W->blob.size();
-    DevMem params, grads, work, dx, dp, dv, dloss;
-    if ((rc = params.ensure(nfl * 4)) || (rc = grads.ensure(nfl * 4)) || (rc = work.ensure(kh::train_workspace_floats(F, C, R, B) * 4)) ||
-        (rc = dx.ensure((size_t)B * 64 * F * 4)) || (rc = dp.ensure((size_t)B * KH_PSIZE * 4)) || (rc = dv.ensure((size_t)B * 4)) ||
-        (rc = dloss.ensure((size_t)B * 2 * 4)))
-        return rc;
-    hipStream_t st;
-    HIPCHK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
-    struct StreamGuard { hipStream_t s; ~StreamGuard() { (void)hipStreamDestroy(s); } } guard{ st };
+    std::lock_guard<std::mutex> train_lock(e->train_mu);      // one trainer per engine at a time (the reference: exclusive lock, nn.cpp:226)
+    if (!e->train) e->train = new TrainCache();
+    TrainCache& tc = *e->train;
+    DevMem &params = tc.params, &grads = tc.grads, &work = tc.work, &dx = tc.dx, &dp = tc.dp, &dv = tc.dv, &dloss = tc.dloss;
+    const bool valu_now = getenv("KAMI_TRAIN_VALU") && atoi(getenv("KAMI_TRAIN_VALU")) != 0;
+    {
+        const void* before[3] = { params.p, work.p, dx.p };
+        if ((rc = params.ensure(nfl * 4)) || (rc = grads.ensure(nfl * 4)) || (rc = work.ensure(kh::train_workspace_floats(F, C, R, B) * 4)) ||
+            (rc = dx.ensure((size_t)B * 64 * F * 4)) || (rc = dp.ensure((size_t)B * KH_PSIZE * 4)) || (rc = dv.ensure((size_t)B * 4)) ||
+            (rc = dloss.ensure((size_t)B * 2 * 4)))
+            return rc;
+        // the recorded step holds buffer addresses, the batch size, the learning rate and the kernel choice
+        if (before[0] != params.p || before[1] != work.p || before[2] != dx.p || tc.B != B || tc.lr != cfg->lr || tc.valu != valu_now) tc.drop_graph();
+        tc.B = B; tc.lr = cfg->lr; tc.valu = valu_now;
+    }
+    if (!tc.st) HIPCHK(hipStreamCreateWithFlags(&tc.st, hipStreamNonBlocking));
+    hipStream_t st = tc.st;
     HIPCHK(hipMemcpyAsync(params.p, W->blob.data(), nfl * 4, hipMemcpyHostToDevice, st));
 
     // nn.cpp:245-262: one engine for the whole call, one shuffle per epoch; staging rows persist
@@ -1310,7 +1366,7 @@ int kh_train(kh_engine* e, const float* inputs, const float* obs_p, const float*
     auto rng = std::default_random_engine{};
     const size_t in_row = (size_t)64 * F;
     // batch staging in page-locked memory (rows persist from batch to batch like the reference's stack buffers)
-    PinMem pin;
+    PinMem& pin = tc.pin;
     const size_t n_in = (size_t)B * in_row, n_p = (size_t)B * KH_PSIZE;
     if (pin.ensure((n_in + n_p + (size_t)B + (size_t)B * 2) * 4)) return KH_ERR_HIP;
     float* next_input = reinterpret_cast<float*>(pin.p);
@@ -1322,11 +1378,8 @@ int kh_train(kh_engine* e, const float* inputs, const float* obs_p, const float*
     const kh::StepBuffers sb{ params.as<float>(), grads.as<float>(), work.as<float>() };
     // A step is ~120 small launches on fixed buffers: recorded once as a graph, replayed per batch (with the
     // tiled conv kernels the host's launch work, not the GPU, bounded a step).  Falls back to plain launches.
-    struct GraphGuard {
-        hipGraph_t g = nullptr; hipGraphExec_t x = nullptr;
-        ~GraphGuard() { if (x) (void)hipGraphExecDestroy(x); if (g) (void)hipGraphDestroy(g); }
-    } graph;
-    bool graph_tried = false;
+    TrainCache& graph = tc;
+    bool& graph_tried = tc.graph_tried;
     HIPCHK(kh::conv_f32_raw_prepare());          // function attributes are not stream work: set them before any capture
     static const bool trace = getenv("KAMI_TRAIN_TRACE") != nullptr;
     for (int epoch = 0; epoch < cfg->epochs; ++epoch) {
