@@ -25,11 +25,9 @@ SOURCES = ["kh_api.hip", "encode.hip", "forward_simple.hip", "tower_mfma.hip", "
 # MFMA results in arch VGPRs: the epilogues read them with VALU ops and would otherwise pay a
 # v_accvgpr_read per value (the kernel runs one wave per SIMD, registers are not scarce).
 EXTRA_FLAGS = {"tower_mfma.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"]}
-if os.environ.get("KAMI_DIAG"):
-    # diagnostic build: compiles the KAMI_TOWER_DBG timing / stamp variants of the tower kernel in
-    # (tools/ab_bench.py, tools/stamprun.py, tools/dbgrun.py); never the shipped configuration
-    EXTRA_FLAGS["tower_mfma.hip"] = EXTRA_FLAGS["tower_mfma.hip"] + ["-DKAMI_TOWER_DIAG"]
-    EXTRA_FLAGS["layers_mfma.hip"] = ["-DKAMI_WIDE_DIAG"]
+# (tools/wide_stamps.py and tools/t128_stamps.py use a separate diagnostic object of layers_mfma.hip built with
+#  -DKAMI_WIDE_DIAG — in-kernel s_memtime stamps — linked into csrc/build/libkamihip_diag.so by tools/build_diag.sh;
+#  the shipped library never contains it, and tower_mfma.hip has no diagnostic variants any more.)
 HIPCC_FLAGS = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-Wall", "-Wno-unused-result", "-Wno-pass-failed",
                "-ffp-contract=fast"]
 

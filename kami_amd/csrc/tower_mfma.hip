@@ -121,8 +121,6 @@ struct Pipe {
     int next;               // chunk index to issue next
     int islot, cslot;       // ring slots: next to fill / next to consume
     unsigned ring;          // LDS byte offset of the ring
-    unsigned long long* stamps;   // DBG 1024 only: s_memtime before / after every step barrier
-    int nstep;
 };
 
 // One wave's quarter of a chunk: two 1 KB LDS-DMA pieces (64 lanes x 16 B each -> LDS[M0 + inst
@@ -152,30 +150,17 @@ __device__ __forceinline__ void pipe_issue(Pipe& p, int wave, int lane)
 //   3. refill slot (c-1) mod D with chunk c+D-1
 // and returns the LDS offset of chunk c+1, which the caller reads into its other register set
 // while the MFMAs of chunk c run.  A chunk is therefore requested D-2 steps before it is needed.
-// DBG (timing experiments only, results are wrong when non-zero): 1 = no s_barrier, 2 = no DMA
-// issue, 4 = no vmcnt wait.
 // VMX: vector-memory operations younger than the ring's that the wait must leave in flight (the
 // stem's first steps run under the tail of the prologue's loads, see the kernel).
-template <int DBG = 0, int VMX = 0>
+template <int VMX = 0>
 __device__ __forceinline__ unsigned pipe_step(Pipe& p, int wave, int lane)
 {
-    unsigned long long t0 = 0, t1 = 0;
-    if (DBG & 1024) t0 = __builtin_amdgcn_s_memtime();
-    if (!(DBG & 4)) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * (RING_D - 3) + VMX) : "memory");
-    if (DBG & 1024) t1 = __builtin_amdgcn_s_memtime();
-    if (!(DBG & 1)) asm volatile("s_barrier" ::: "memory");
-    if (DBG & 1024) {
-        const unsigned long long t2 = __builtin_amdgcn_s_memtime();
-        if (p.stamps && lane == 0 && p.nstep < 256) {
-            unsigned long long* d = p.stamps + ((size_t)wave * 256 + p.nstep) * 3;
-            d[0] = t0; d[1] = t1; d[2] = t2;
-        }
-        ++p.nstep;
-    }
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * (RING_D - 3) + VMX) : "memory");
+    asm volatile("s_barrier" ::: "memory");
     // Nothing moves across the step boundary: hipcc otherwise hoists the next step's MFMAs up to
     // their operand loads and the register double-buffering collapses into load->wait->MFMA.
     __builtin_amdgcn_sched_barrier(0);
-    if (!(DBG & 2)) pipe_issue(p, wave, lane);
+    pipe_issue(p, wave, lane);
     p.cslot = (p.cslot + 1 == RING_D) ? 0 : p.cslot + 1;
     return p.ring + p.cslot * CHUNK;
 }
@@ -210,15 +195,6 @@ __device__ __forceinline__ constexpr unsigned b_offset(int kk, int stride)
     return (unsigned)((TAPS == 9 ? ((tap / 3) * PITCH + (tap % 3)) * stride : 0) + ks * 32);
 }
 
-// (DBG 1024) extra stamp inside a layer boundary: slot b, point k
-__device__ __forceinline__ void bstamp(Pipe& p, int wave, int lane, int b, int k)
-{
-    __builtin_amdgcn_sched_barrier(0);
-    const unsigned long long t = __builtin_amdgcn_s_memtime();
-    if (p.stamps && lane == 0 && b < 64) p.stamps[4 * 256 * 3 + ((size_t)wave * 64 + b) * 4 + k] = t;
-    __builtin_amdgcn_sched_barrier(0);
-}
-
 struct NoHook { __device__ __forceinline__ void operator()() const {} };
 
 // RELAX / VMX: the first RELAX steps wait with VMX extra operations allowed in flight; hook() runs
@@ -227,7 +203,7 @@ struct NoHook { __device__ __forceinline__ void operator()() const {} };
 // output of the previous layer, see Packed) instead of the LDS image; CF as in b_offset.  With
 // NREG > 0 nothing is read from the image before the first step's barrier, which then also orders
 // the previous epilogue's image writes of all waves before the other taps' reads.
-template <typename T, int TAPS, int KS, int MS, int PAR, int DBG = 0, int RELAX = 0, int VMX = 0, int HOOK_AT = -1,
+template <typename T, int TAPS, int KS, int MS, int PAR, int RELAX = 0, int VMX = 0, int HOOK_AT = -1,
           int NREG = 0, bool CF = false, int TAILV = 0, class Hook = NoHook>
 __device__ __forceinline__ void gemm_layer(Pipe& p, const char* smem, int wave, int lane,
                                            unsigned b_base, int stride, f32x16 (&acc)[MS],
@@ -247,16 +223,10 @@ __device__ __forceinline__ void gemm_layer(Pipe& p, const char* smem, int wave, 
     for (int n = 0; n < S::NCH; ++n) {
         const int cur = (PAR + n) & 1, nxt = cur ^ 1;
         if (n == HOOK_AT) hook();
-        const unsigned a_off = (n < RELAX ? pipe_step<DBG, VMX>(p, wave, lane) : pipe_step<DBG>(p, wave, lane)) + lane * 16;
+        const unsigned a_off = (n < RELAX ? pipe_step<VMX>(p, wave, lane) : pipe_step<>(p, wave, lane)) + lane * 16;
 #pragma unroll
-        for (int f = 0; f < 8; ++f) {
-            if (DBG & 16) A[nxt][f] = A[cur][f];
-            else A[nxt][f] = *reinterpret_cast<const V*>(smem + a_off + f * 1024);
-        }
-        if ((DBG & 8) && n + 1 < S::NCH) {
-#pragma unroll
-            for (int k = 0; k < KPC; ++k) B[nxt][k] = B[cur][k];
-        } else if (n + 1 < S::NCH) {
+        for (int f = 0; f < 8; ++f) A[nxt][f] = *reinterpret_cast<const V*>(smem + a_off + f * 1024);
+        if (n + 1 < S::NCH) {
 #pragma unroll
             for (int k = 0; k < KPC; ++k) {
                 if ((n + 1) * KPC + k < NREG) B[nxt][k] = breg[(n + 1) * KPC + k];
@@ -285,22 +255,14 @@ __device__ __forceinline__ void gemm_layer(Pipe& p, const char* smem, int wave, 
 #pragma unroll
         for (int k = 0; k < KPC; ++k)
 #pragma unroll
-            for (int ms = 0; ms < MS; ++ms) {
-                if (DBG & 32) asm volatile("" ::"v"(A[cur][k * MS + ms]), "v"(B[cur][k]));
-                else acc[ms] = Elem<T>::mfma(A[cur][k * MS + ms], B[cur][k], acc[ms]);
-            }
+            for (int ms = 0; ms < MS; ++ms) acc[ms] = Elem<T>::mfma(A[cur][k * MS + ms], B[cur][k], acc[ms]);
         // Pin the interleave: the next chunk's operand reads go out two per MFMA from the top of
         // the step.  Left alone hipcc sinks them to the end of the step and their latency lands on
-        // the next barrier; issued as one burst (DBG 512) they measured 8 % slower than paced.
-        if (DBG & 512) {
-            __builtin_amdgcn_sched_group_barrier(0x100, 8 + KPC, 0);
-            __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);
-        } else {
+        // the next barrier; issued as one burst they measured 8 % slower than paced.
 #pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);   // DS read
-                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // MFMA
-            }
+        for (int i = 0; i < 8; ++i) {
+            __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);   // DS read
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // MFMA
         }
     }
 }
@@ -491,7 +453,7 @@ __device__ __forceinline__ void ingest_half(const float4_u (&v)[4][2], int hh, c
 
 // ---------------------------------------------------------------- the kernel
 // KS_STEM = padded input planes / 16 (2 for F <= 32, 8 for F <= 128).
-template <typename T, int KS_STEM, int DBG = 0>
+template <typename T, int KS_STEM>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void tower_kernel(TowerArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -531,8 +493,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     Pipe pipe;
     pipe.stream = a.wstream; pipe.nch = a.nchunks; pipe.next = 0; pipe.islot = 0; pipe.cslot = 0;
     pipe.ring = LDS_RING;
-    pipe.stamps = ((DBG & 1024) && blockIdx.x == 0) ? reinterpret_cast<unsigned long long*>(a.logits) : nullptr;
-    pipe.nstep = 0;
 #pragma unroll
     for (int i = 0; i < RING_D - 1; ++i) pipe_issue(pipe, wave, lane);
 
@@ -595,7 +555,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         //          bytes.  Loads are clamped into the row / batch and masked afterwards so that every
         //          wave issues exactly 8 loads per half (the counted vmcnt waits depend on it).
         if (KS_STEM == 8) {
-            if (!(DBG & 64)) {
+            {
 #pragma unroll
                 for (int hh = 0; hh < 2; ++hh)
 #pragma unroll
@@ -623,10 +583,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 #pragma unroll
                 for (int k = 0; k < SSTR / 16; ++k) *reinterpret_cast<u32x4*>(ds + k * 16) = z;
             }
-            if (!(DBG & 64)) ingest_half<T>(pl[0], 0, smem + LDS_ST, SSTR, SBOARD, b0, tid, lane, a);
+            ingest_half<T>(pl[0], 0, smem + LDS_ST, SSTR, SBOARD, b0, tid, lane, a);
         } else
         // ---- 1. planes fp32 [b][64][F] -> T in S (interior pixels, all FP channels); halos zeroed
-        if (!(DBG & 64)) {
+        {
             // item i = tid + 256*j -> (board, pixel, 8-channel chunk); a wave covers 4 whole pixels
             float vin[NIT][8];
             const int c0 = (tid % CH) * 8;
@@ -704,12 +664,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                 // pass 1 (planes 0..63): its first RING_D - 2 steps only need chunks that were requested
                 // before the plane loads, so their waits leave the second half's loads in flight
                 auto ingest_h1 = [&]() {
-                    if (!(DBG & 64)) ingest_half<T>(pl[1], 1, smem + LDS_ST, SSTR, SBOARD, b0, tid, lane, a);
+                    ingest_half<T>(pl[1], 1, smem + LDS_ST, SSTR, SBOARD, b0, tid, lane, a);
                 };
-                gemm_layer<T, 9, 4, 2, 0, DBG & 1024, RING_D - 2, VMX, RING_D - 2>(pipe, smem, wave, lane, sin, SSTR, acc, A, ingest_h1);
-                gemm_layer<T, 9, 4, 2, 1, DBG & 1024>(pipe, smem, wave, lane, sin + 128, SSTR, acc, A);   // pass 2: planes 64..127
+                gemm_layer<T, 9, 4, 2, 0, RING_D - 2, VMX, RING_D - 2>(pipe, smem, wave, lane, sin, SSTR, acc, A, ingest_h1);
+                gemm_layer<T, 9, 4, 2, 1>(pipe, smem, wave, lane, sin + 128, SSTR, acc, A);   // pass 2: planes 64..127
             } else {
-                gemm_layer<T, 9, KS_STEM, 2, 0, DBG & 1024>(pipe, smem, wave, lane, sin, SSTR, acc, A);
+                gemm_layer<T, 9, KS_STEM, 2, 0>(pipe, smem, wave, lane, sin, SSTR, acc, A);
             }
             epilogue_residual<T, false>(acc, xf, xk);
             store_packed<2>(xk, smem, xout, h);
@@ -738,37 +698,17 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             acc[0] = accn[0]; acc[1] = accn[1];
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");          // own image writes done before the step barrier
             acc_init<2>(accn, shift3 + (2 + 2 * r) * TW_CP, h);
-            gemm_layer<T, 9, TW_CP / 16, 2, P1, DBG, 0, 0, -1, 4, true, (DBG & 8192) ? 0 : 6>(pipe, smem, wave, lane, xin, XSTR, acc, A, NoHook(), bf);
+            gemm_layer<T, 9, TW_CP / 16, 2, P1, 0, 0, -1, 4, true, 6>(pipe, smem, wave, lane, xin, XSTR, acc, A, NoHook(), bf);
             Packed<2> tk;
-            if (DBG & 1024) bstamp(pipe, wave, lane, 2 * r, 0);
-            if (DBG & 16384) {          // (timing variant) the epilogue arithmetic twice
-                epilogue_pack<T, 2>(acc, tk);
-#pragma unroll
-                for (int ms = 0; ms < 2; ++ms) asm volatile("" : "+v"(acc[ms]), "+v"(tk.o[ms][0]), "+v"(tk.o[ms][1]), "+v"(tk.o[ms][2]), "+v"(tk.o[ms][3]));
-            }
             epilogue_pack<T, 2>(acc, tk);
-            if (DBG & 32768) { store_packed<2>(tk, smem, tout, h); asm volatile("" ::: "memory"); }
-            if (DBG & 65536) lds_barrier();
             store_packed<2>(tk, smem, tout, h);
-            if (DBG & 1024) bstamp(pipe, wave, lane, 2 * r, 1);
             packed_fragments<T, 2>(tk, bf);
             acc[0] = accn[0]; acc[1] = accn[1];
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            if (DBG & 1024) bstamp(pipe, wave, lane, 2 * r, 2);
             acc_init<2>(accn, shift3 + (3 + 2 * r) * TW_CP, h);         // (past the last block: the policy shifts, unused)
-            gemm_layer<T, 9, TW_CP / 16, 2, P1 ^ 1, DBG, 0, 0, -1, 4, true, (DBG & 8192) ? 0 : 11>(pipe, smem, wave, lane, tin, XSTR, acc, A, NoHook(), bf);
-            if (DBG & 1024) bstamp(pipe, wave, lane, 2 * r + 1, 0);
-            if (DBG & 16384) {
-                f32x16 xf2[2] = { xf[0], xf[1] };
-                epilogue_residual<T, true>(acc, xf2, xk);
-#pragma unroll
-                for (int ms = 0; ms < 2; ++ms) asm volatile("" : "+v"(acc[ms]), "+v"(xf[ms]), "+v"(xk.o[ms][0]), "+v"(xk.o[ms][1]), "+v"(xk.o[ms][2]), "+v"(xk.o[ms][3]), "+v"(xf2[ms]));
-            }
+            gemm_layer<T, 9, TW_CP / 16, 2, P1 ^ 1, 0, 0, -1, 4, true, 11>(pipe, smem, wave, lane, tin, XSTR, acc, A, NoHook(), bf);
             epilogue_residual<T, true>(acc, xf, xk);
-            if (DBG & 32768) { store_packed<2>(xk, smem, xout, h); asm volatile("" ::: "memory"); }
-            if (DBG & 65536) lds_barrier();
             store_packed<2>(xk, smem, xout, h);
-            if (DBG & 1024) bstamp(pipe, wave, lane, 2 * r + 1, 1);
         }
 
         // ---- 4a. value head, first half: valueconv + vbatchnorm + relu (nn.cpp:83-85) on the fp32
@@ -814,22 +754,19 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             V bf[4];
             packed_fragments<T, 2>(xk, bf);
             acc_init<4>(acc, pshift1, h);
-            gemm_layer<T, 1, TW_CP / 16, 4, P1, DBG & 1024, 2, 17, -1, 4>(pipe, smem, wave, lane, 0, 0, acc, A, NoHook(), bf);
+            gemm_layer<T, 1, TW_CP / 16, 4, P1, 2, 17, -1, 4>(pipe, smem, wave, lane, 0, 0, acc, A, NoHook(), bf);
             epilogue_pack<T, 4>(acc, pk);
         }
-        // ---- 4e'. (timing variant) value FC before the policy steps: +0.13 us
-        if ((DBG & 2048) && !(DBG & 256)) value_fc(a, fcw, fcbias, v64, b0, tid, lane);
-
         // ---- 4c. policyconv2 (+bias): -> logits L[board][pixel*73 + plane]      nn.cpp:75-79
         {
             f32x16 acc[4];                  // 73 planes padded to 128 rows: whole 2-k-step chunks
             V bf[8];
             packed_fragments<T, 4>(pk, bf);
             acc_init<4>(acc, pbias2, h);
-            gemm_layer<T, 1, KH_POLICY_MID / 16, 4, P1, DBG & 1024, RING_D - 4, 17, -1, 8>(pipe, smem, wave, lane, 0, 0, acc, A, NoHook(), bf);
+            gemm_layer<T, 1, KH_POLICY_MID / 16, 4, P1, RING_D - 4, 17, -1, 8>(pipe, smem, wave, lane, 0, 0, acc, A, NoHook(), bf);
             if (P1) gemm_dummy<T, 1>(pipe, smem, wave, lane, A);      // stream parity back to 0 for the next group
             float* lrow = reinterpret_cast<float*>(smem + LDS_L + wb * LBOARD) + (py * 8 + px) * KH_POLICY_PLANES;
-            if (!(DBG & 4096)) {    // raw logits to LDS, softmax below
+            {    // raw logits to LDS, softmax below
 #pragma unroll
                 for (int ms = 0; ms < 3; ++ms)      // planes >= 96 are padding
 #pragma unroll
@@ -840,80 +777,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                             if (plane < KH_POLICY_PLANES) lrow[plane] = acc[ms][4 * g + i];
                         }
                 lds_barrier();
-            } else if (!(DBG & 128)) {
-                // ---- 4d'. (timing variant, +-0) softmax straight from the accumulators: max -> exp / sum in
-                //           registers, one transposing pass through LDS
-                const bool live = (b0 + wb) < a.B;
-                if (a.logits && live && !(DBG & 1024)) {     // diagnostic output (kh_infer_full): uncoalesced, off the timed path
-                    float* lg = a.logits + (size_t)(b0 + wb) * KH_PSIZE + (py * 8 + px) * KH_POLICY_PLANES;
-#pragma unroll
-                    for (int ms = 0; ms < 3; ++ms)
-#pragma unroll
-                        for (int g = 0; g < 4; ++g)
-#pragma unroll
-                            for (int i = 0; i < 4; ++i) {
-                                const int plane = ms * 32 + 8 * g + 4 * h + i;
-                                if (plane < KH_POLICY_PLANES) lg[plane] = acc[ms][4 * g + i];
-                            }
-                }
-                float m = -INFINITY;
-#pragma unroll
-                for (int ms = 0; ms < 3; ++ms)
-#pragma unroll
-                    for (int g = 0; g < 4; ++g)
-#pragma unroll
-                        for (int i = 0; i < 4; ++i) {
-                            const int plane = ms * 32 + 8 * g + 4 * h + i;
-                            if (ms * 32 + 8 * g + i < KH_POLICY_PLANES)      // (false for both h: no code)
-                                m = fmaxf(m, plane < KH_POLICY_PLANES ? acc[ms][4 * g + i] : -INFINITY);
-                        }
-                m = wave_max_f(m);
-                if (lane == 0) red[wave] = m;
-                lds_barrier();
-                m = fmaxf(red[wb * 2], red[wb * 2 + 1]);
-                float sum = 0.0f;
-#pragma unroll
-                for (int ms = 0; ms < 3; ++ms)
-#pragma unroll
-                    for (int g = 0; g < 4; ++g)
-#pragma unroll
-                        for (int i = 0; i < 4; ++i) {
-                            const int plane = ms * 32 + 8 * g + 4 * h + i;
-                            if (ms * 32 + 8 * g + i < KH_POLICY_PLANES && plane < KH_POLICY_PLANES) {
-                                const float e = __expf(acc[ms][4 * g + i] - m);
-                                sum += e;
-                                lrow[plane] = e;
-                            }
-                        }
-                sum = wave_sum_f(sum);
-                if (lane == 0) red[4 + wave] = sum;
-                lds_barrier();
-                const float inv = 1.0f / (red[4 + wb * 2] + red[4 + wb * 2 + 1]);
-                const int tt = tid & 127;
-                const float4* L4 = reinterpret_cast<const float4*>(smem + LDS_L + wb * LBOARD);
-                constexpr int NQ = KH_PSIZE / 4;               // 1168 float4 = 9 * 128 + 16
-                bool nan = false;
-                if (live) {
-                    using f4 = float __attribute__((ext_vector_type(4)));
-                    f4* po = reinterpret_cast<f4*>(a.policy + (size_t)(b0 + wb) * KH_PSIZE);
-#pragma unroll
-                    for (int k = 0; k < 10; ++k) {
-                        const int q = tt + 128 * k;
-                        if (q < NQ) {
-                            const float4 v = L4[q];
-                            const f4 o = { v.x * inv, v.y * inv, v.z * inv, v.w * inv };
-                            nan |= (o.x != o.x) | (o.y != o.y) | (o.z != o.z) | (o.w != o.w);
-                            __builtin_nontemporal_store(o, po + q);        // write-once stream
-                        }
-                    }
-                }
-                if (__any(nan) && lane == 0) atomicOr(&a.flags[0], 1);
             }
         }
 
         // ---- 4d. softmax over all 4672 logits of a board (nn.cpp:80): 128 threads per board, one LDS
         //          pass, each thread keeps its <= 10 float4 in registers
-        if (!(DBG & 4096) && !(DBG & 128)) {
+        {
             const int bb = tid >> 7, tt = tid & 127;
             const bool live = (b0 + bb) < a.B;
             const float4* L4 = reinterpret_cast<const float4*>(smem + LDS_L + bb * LBOARD);
@@ -924,7 +793,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                 const int q = tt + 128 * k;
                 v[k] = (q < NQ) ? L4[q] : make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
             }
-            if (a.logits && live && !(DBG & 1024)) {
+            if (a.logits && live) {
                 float4* lo = reinterpret_cast<float4*>(a.logits + (size_t)(b0 + bb) * KH_PSIZE);
 #pragma unroll
                 for (int k = 0; k < 10; ++k)
@@ -967,24 +836,24 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         }
 
         // ---- 4e. value head, second half: valuefc + tanh -> [B][256]            nn.cpp:86-88
-        if (!(DBG & 2048) && !(DBG & 256)) value_fc(a, fcw, fcbias, v64, b0, tid, lane);
+        value_fc(a, fcw, fcbias, v64, b0, tid, lane);
         lds_barrier();      // L / v64 are dead; the next group may overwrite them
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // drain the prefetch ring before exit
 }
 
-template <typename T, int KS_STEM, int DBG = 0> static hipError_t launch(const TowerArgs& a, int grid, hipStream_t s)
+template <typename T, int KS_STEM> static hipError_t launch(const TowerArgs& a, int grid, hipStream_t s)
 {
     constexpr int FP = KS_STEM * 16;
     const int lds = LDS_ST + st_size(FP) + tower_par_floats(a.R) * 4;
     static std::atomic<bool> attr_done{ false };      // engines are called from many host threads; setting it twice is harmless
     if (!attr_done.load(std::memory_order_acquire)) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&tower_kernel<T, KS_STEM, DBG>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&tower_kernel<T, KS_STEM>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) return e;
         attr_done.store(true, std::memory_order_release);
     }
-    hipLaunchKernelGGL((tower_kernel<T, KS_STEM, DBG>), dim3(grid), dim3(256), lds, s, a);
+    hipLaunchKernelGGL((tower_kernel<T, KS_STEM>), dim3(grid), dim3(256), lds, s, a);
     return hipGetLastError();
 }
 
@@ -997,44 +866,6 @@ hipError_t launch_tower(int dtype, int FP, const TowerArgs& a, int num_cus, hipS
 {
     const int ngroups = (a.B + TW_NB - 1) / TW_NB;
     const int grid = ngroups < num_cus ? ngroups : num_cus;      // one workgroup per CU (LDS-bound residency)
-#ifdef KAMI_TOWER_DIAG   // diagnostic variants (timing experiments, step stamps): KAMI_DIAG=1 python -m kami_amd.build
-    const int dbg = getenv("KAMI_TOWER_DBG") ? atoi(getenv("KAMI_TOWER_DBG")) : 0;   // timing experiments (read per launch: in-process A/B, tools/ab_bench.py)
-    static bool said = false;
-    if (dbg && !said) { fprintf(stderr, "[kamihip] KAMI_TOWER_DBG=%d (timing experiment: results are WRONG) dtype=%d FP=%d\n", dbg, dtype, FP); said = true; }
-    if (dbg && dtype == KH_BF16 && FP == 128) {
-        switch (dbg) {
-        case 1: return launch<__bf16, 8, 1>(a, grid, s);
-        case 2: return launch<__bf16, 8, 2>(a, grid, s);
-        case 3: return launch<__bf16, 8, 3>(a, grid, s);
-        case 7: return launch<__bf16, 8, 7>(a, grid, s);
-        case 8: return launch<__bf16, 8, 8>(a, grid, s);
-        case 16: return launch<__bf16, 8, 16>(a, grid, s);
-        case 24: return launch<__bf16, 8, 24>(a, grid, s);
-        case 32: return launch<__bf16, 8, 32>(a, grid, s);
-        case 58: return launch<__bf16, 8, 58>(a, grid, s);
-        case 63: return launch<__bf16, 8, 63>(a, grid, s);
-        case 64: return launch<__bf16, 8, 64>(a, grid, s);
-        case 128: return launch<__bf16, 8, 128>(a, grid, s);
-        case 256: return launch<__bf16, 8, 256>(a, grid, s);
-        case 448: return launch<__bf16, 8, 448>(a, grid, s);
-        case 512: return launch<__bf16, 8, 512>(a, grid, s);
-        case 1024: return launch<__bf16, 8, 1024>(a, grid, s);
-        case 26: return launch<__bf16, 8, 26>(a, grid, s);
-        case 34: return launch<__bf16, 8, 34>(a, grid, s);
-        case 56: return launch<__bf16, 8, 56>(a, grid, s);
-        case 27: return launch<__bf16, 8, 27>(a, grid, s);
-        case 2048: return launch<__bf16, 8, 2048>(a, grid, s);
-        case 4096: return launch<__bf16, 8, 4096>(a, grid, s);
-        case 6144: return launch<__bf16, 8, 6144>(a, grid, s);
-        case 8192: return launch<__bf16, 8, 8192>(a, grid, s);
-        case 16384: return launch<__bf16, 8, 16384>(a, grid, s);
-        case 32768: return launch<__bf16, 8, 32768>(a, grid, s);
-        case 65536: return launch<__bf16, 8, 65536>(a, grid, s);
-        case 114688: return launch<__bf16, 8, 114688>(a, grid, s);
-        default: break;
-        }
-    }
-#endif
     if (dtype == KH_BF16) return FP == 32 ? launch<__bf16, 2>(a, grid, s) : launch<__bf16, 8>(a, grid, s);
     return FP == 32 ? launch<_Float16, 2>(a, grid, s) : launch<_Float16, 8>(a, grid, s);
 }
