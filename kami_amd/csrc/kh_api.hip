@@ -130,6 +130,8 @@ struct Weights {
     // per-layer MFMA path for wide nets (layers_mfma.hip)
     DevMem ly_w, ly_shift, ly_misc;      // ly_misc: vw[CP], fcw[256*64], fcb[256]
     DevMem ly_w4;                        // 3x3 layers once more, packed for conv4_mfma_kernel
+    DevMem ly_w2b;                       // stem + tower packed for tower256_kernel (256-channel blocks)
+    bool ly_w2b_ok = false;
     DevMem ly_wh;                        // policyconv + policyconv2 packed for policy_head4_kernel
     bool ly_wh_ok = false;
     std::vector<size_t> ly_w_off, ly_shift_off, ly_w4_off;
@@ -226,17 +228,19 @@ void pack_layer_generic(uint16_t* o, int dtype, const float* w, const float* sca
 // channels x 128 output channels, [Co/128][Ci/64][tap][half][ks2][ms 0..3][lane][8] — the reduction walks in the same
 // order as above (64-channel slices, then taps, then k-steps), so both kernels produce the same bits.
 void pack_layer_wide128(uint16_t* o, int dtype, const float* w, const float* scale,
-                        int Co, int Ci, int taps, int CoP, int CiP)
+                        int Co, int Ci, int taps, int CoP, int CiP, int CBC = 128)
 {
+    // CBC: output channels per block — 128 (conv4_mfma_kernel, tower128_kernel, policy_head4_kernel) or 256
+    // (tower256_kernel: eight row tiles per k-step, one k-step per 8 KB chunk)
     const bool bf = dtype == KH_BF16;
-    for (int cb = 0; cb < CoP / 128; ++cb)
+    for (int cb = 0; cb < CoP / CBC; ++cb)
         for (int slice = 0; slice < CiP / 64; ++slice)
             for (int tap = 0; tap < taps; ++tap)
                 for (int kk = 0; kk < 4; ++kk)                  // kk = 2 * half + ks2
-                    for (int ms = 0; ms < 4; ++ms)
+                    for (int ms = 0; ms < CBC / 32; ++ms)
                         for (int l = 0; l < 64; ++l) {
                             const int r = l & 31, h = l >> 5, ks = slice * 4 + kk;
-                            const int co = cb * 128 + ms * 32 + r, ci0 = ks * 16 + 8 * h;
+                            const int co = cb * CBC + ms * 32 + r, ci0 = ks * 16 + 8 * h;
                             const float sc = scale ? (co < Co ? scale[co] : 0.0f) : 1.0f;
                             const float* src = w + ((size_t)co * Ci + ci0) * taps + tap;
                             for (int j = 0; j < 8; ++j) {
@@ -273,12 +277,13 @@ int build_layers(Weights& W, const HostNet& n, int dtype, int F, int C, int R)
     if (CP > 256 || FP > 256) return KH_OK;      // not covered: ly_ok stays false
     // Every layer's fragments are packed by its own job into its own slice: the jobs run on a few host threads (this is
     // on the trainer's path too — kh_train installs its result here — and a 20x256 net is 48 M fragments' worth).
-    std::vector<uint16_t> w, w4, wh;
+    std::vector<uint16_t> w, w4, wh, w2b;
     std::vector<float> wf;
     std::vector<float> shift;
     struct Job { int kind; size_t off; const float* wt; std::vector<float> sc; int Co, Ci, taps, CoP, CiP; };   // kind 0 generic, 1 wide128, 2 f32, 3 head
     std::vector<Job> jobs;
-    size_t nw = 0, nw4 = 0, nwf = 0, nwh = 0;
+    size_t nw = 0, nw4 = 0, nwf = 0, nwh = 0, nw2b = 0;
+    const bool want2b = !f32 && CP == 256 && FP == 128;      // tower256_kernel's shape
     std::vector<float> sc(256), sh(256);
     auto add = [&](const float* wt, const ConvBN* bn, const float* bias, int Co, int Ci, int taps, int CoP, int CiP) {
         W.ly_shift_off.push_back(shift.size());
@@ -293,6 +298,7 @@ int build_layers(Weights& W, const HostNet& n, int dtype, int F, int C, int R)
             if (taps == 9 && CoP % 128 == 0 && (CiP == 128 || CiP == 256)) {     // conv4_mfma_kernel's shapes
                 W.ly_w4_off.back() = nw4; jobs.push_back({ 1, nw4, wt, scv, Co, Ci, taps, CoP, CiP }); nw4 += n;
             }
+            if (want2b && taps == 9) { jobs.push_back({ 4, nw2b, wt, scv, Co, Ci, taps, CoP, CiP }); nw2b += n; }
         }
         for (int i = 0; i < CoP; ++i) shift.push_back(i < Co ? sh[i] : 0.0f);
     };
@@ -307,7 +313,7 @@ int build_layers(Weights& W, const HostNet& n, int dtype, int F, int C, int R)
         jobs.push_back({ 3, nwh, n.p2w, std::vector<float>(), KH_POLICY_PLANES, KH_POLICY_MID, 1, 128, KH_POLICY_MID });
         nwh += (size_t)128 * KH_POLICY_MID;
     }
-    w.resize(nw); w4.resize(nw4); wf.resize(nwf); wh.resize(nwh);
+    w.resize(nw); w4.resize(nw4); wf.resize(nwf); wh.resize(nwh); w2b.resize(nw2b);
     {
         std::atomic<size_t> next{ 0 };
         auto run = [&]() {
@@ -317,6 +323,7 @@ int build_layers(Weights& W, const HostNet& n, int dtype, int F, int C, int R)
                 if (jb.kind == 0) pack_layer_generic(w.data() + jb.off, dtype, jb.wt, scp, jb.Co, jb.Ci, jb.taps, jb.CoP, jb.CiP);
                 else if (jb.kind == 1) pack_layer_wide128(w4.data() + jb.off, dtype, jb.wt, scp, jb.Co, jb.Ci, jb.taps, jb.CoP, jb.CiP);
                 else if (jb.kind == 2) pack_layer_f32(wf.data() + jb.off, jb.wt, scp, jb.Co, jb.Ci, jb.taps, jb.CoP, jb.CiP);
+                else if (jb.kind == 4) pack_layer_wide128(w2b.data() + jb.off, dtype, jb.wt, scp, jb.Co, jb.Ci, jb.taps, jb.CoP, jb.CiP, 256);
                 else pack_layer_wide128(wh.data() + jb.off, dtype, jb.wt, scp, jb.Co, jb.Ci, jb.taps, jb.CoP, jb.CiP);
             }
         };
@@ -340,6 +347,11 @@ int build_layers(Weights& W, const HostNet& n, int dtype, int F, int C, int R)
     if (!w4.empty()) {
         if (W.ly_w4.ensure(w4.size() * 2)) return KH_ERR_HIP;
         HIPCHK(hipMemcpy(W.ly_w4.p, w4.data(), w4.size() * 2, hipMemcpyHostToDevice));
+    }
+    if (!w2b.empty()) {
+        if (W.ly_w2b.ensure(w2b.size() * 2)) return KH_ERR_HIP;
+        HIPCHK(hipMemcpy(W.ly_w2b.p, w2b.data(), w2b.size() * 2, hipMemcpyHostToDevice));
+        W.ly_w2b_ok = true;
     }
     if (!wh.empty()) {
         if (W.ly_wh.ensure(wh.size() * 2)) return KH_ERR_HIP;
@@ -663,6 +675,7 @@ int forward_layers(kh_engine* e, const Weights& W, Slot& s, const float* d_in, i
     L.shift = W.ly_shift.as<float>(); L.shift_off = W.ly_shift_off.data();
     L.vw = W.ly_misc.as<float>(); L.vshift = W.ly_vshift;
     L.wh = W.ly_wh_ok ? W.ly_wh.as<unsigned short>() : nullptr;
+    L.w2b = W.ly_w2b_ok ? W.ly_w2b.as<unsigned short>() : nullptr;
     L.policy = d_policy; L.flags = flags; L.want_logits = d_logits_out != nullptr;
     L.fcw = W.ly_misc.as<float>() + W.ly_CP; L.fcb = L.fcw + (size_t)KH_VALUE_WIDTH * 64; L.vfull = d_vfull;
     HIPCHK(kh::launch_layers(e->cfg.dtype, L, st));              // tower, policy head + softmax (nn.cpp:72-80), value head (nn.cpp:83-88)

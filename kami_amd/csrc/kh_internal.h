@@ -82,6 +82,7 @@ struct LayersArgs {
     const size_t* shift_off;       // HOST array: float offset of each layer in shift
     const float* vw;               // [CP] valueconv weight * bn scale (device)
     float vshift;
+    const unsigned short* w2b;     // stem + tower packed for tower256_kernel (device; nullptr: not eligible)
     const unsigned short* wh;      // policy head packed for policy_head4_kernel (device; nullptr: not eligible)
     float* policy;                 // [B][4672]: launch_layers runs the softmax itself (nn.cpp:80)
     int* flags;                    // NaN flags ([0] policy, [1] value)

@@ -786,6 +786,201 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 }
 
 // ---------------------------------------------------------------------------------------------
+// tower256_kernel — the whole 3x3 stack of a 256-filter net (BASELINE configs[4]'s) in one launch, activations on chip.
+// Four 256-channel board images do not fit LDS, so a workgroup is TWO boards (2 x 63 360 B).  The first version kept
+// tower128's roles — a wave = 32 pixels x all 256 channels, weights through an LDS ring — and ran its 8-MFMA steps in
+// 413 clocks instead of 256: every wave re-read the same eight A fragments (36 KB of LDS reads per step) next to the
+// ring's 8 KB of LDS-DMA writes, more LDS time than MFMA time, and a workgroup barrier per step.  So the roles are
+// turned: a wave owns 64 OUTPUT CHANNELS x all 128 pixels of the two boards (2 row tiles x 4 pixel tiles = 8
+// accumulators).  Its two A fragments per k-step are nobody else's, so they go global -> registers directly (16 bytes
+// per lane, requested four k-steps ahead; every weight byte still enters the CU once), and LDS only serves the four
+// B fragments (16 KB per step for the workgroup, a quarter of its bandwidth): no ring, no LDS-DMA, no barrier inside a
+// layer.  A layer boundary is two workgroup barriers (everybody has read the old image; everybody has written its 64
+// channels of the new one) around tower128's epilogue.  The stem has 128 (padded) input planes = 72 k-steps, the other
+// layers 144.  Weights: pack_layer_wide128(..., CBC = 256): [Ci/64][tap][k-step][row tile 0..7][lane][8] — the
+// per-layer kernels' reduction order, so the same bits.
+struct Tower256Args {
+    const float* planes;          // fp32 [B][64][F], F <= 128, 16-byte aligned
+    int F;
+    unsigned magic;               // ceil(2^32 / F)
+    const unsigned short* w;      // 72 + 2R x 144 k-steps of 8 KB
+    const float* shift;           // (1 + 2R) x 256 folded BatchNorm shifts
+    unsigned short* out;          // T [B][64][256]: the residual stream after the last block
+    int B, R;
+};
+
+template <typename T>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void tower256_kernel(Tower256Args a)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    using V = typename Elem<T>::vec8;
+    const int tid = threadIdx.x, lane = tid & 63, h = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    constexpr int CH = 256;
+    constexpr int stride = CH * 2 + 16;                     // 528 B per pixel: 33 16-byte slots, odd
+    constexpr int board_bytes = NPIX * stride;
+    const int b0 = blockIdx.x * 2;
+    const int NL = 1 + 2 * a.R;
+    const int NKT = 72 + 2 * a.R * 144;                     // k-steps of the whole stack
+    char* img = smem;
+    // this wave's A fragments of k-step k: row tiles 2 wave, 2 wave + 1 of the step's eight
+    const char* wl = reinterpret_cast<const char*>(a.w) + (size_t)(2 * wave) * 1024 + lane * 16;
+    V Areg[4][2];
+    auto load_a = [&](int slot, int k) {
+        const size_t kc = (size_t)(k < NKT ? k : NKT - 1) * CHUNKB;      // past the end: a harmless re-read
+        Areg[slot][0] = *reinterpret_cast<const V*>(wl + kc);
+        Areg[slot][1] = *reinterpret_cast<const V*>(wl + kc + 1024);
+    };
+#pragma unroll
+    for (int j = 0; j < 4; ++j) load_a(j, j);
+    {
+        // fp32 planes -> T in the image (tower128_kernel's ingest, two boards): everything zeroed first (halo, planes
+        // F..255 of the image: the stem only reads 0..127), then float4 pieces scattered to (pixel, plane)
+        const u32x4 z = { 0, 0, 0, 0 };
+        for (int i = tid; i < 2 * board_bytes / 16; i += 256) *reinterpret_cast<u32x4*>(img + i * 16) = z;
+        const int F = a.F, pieces = 16 * F;
+        constexpr int NU = 16;                               // 2 boards x 16 F pieces / 256 threads <= 16 for F <= 128
+        float4 v[NU];
+#pragma unroll
+        for (int u = 0; u < NU; ++u) {
+            const int i = tid + u * 256;
+            const int bb = __umulhi((unsigned)i, a.magic) >> 4;
+            const int q = i - bb * pieces;
+            v[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (bb < 2 && b0 + bb < a.B) v[u] = *reinterpret_cast<const float4*>(a.planes + ((size_t)(b0 + bb) * 64) * F + 4 * q);
+        }
+        __syncthreads();
+#pragma unroll
+        for (int u = 0; u < NU; ++u) {
+            const int i = tid + u * 256;
+            const int bb = __umulhi((unsigned)i, a.magic) >> 4;
+            if (bb >= 2) continue;
+            const int q = i - bb * pieces;
+            int p = __umulhi((unsigned)(4 * q), a.magic), c = 4 * q - p * F;
+            const float e[4] = { v[u].x, v[u].y, v[u].z, v[u].w };
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int pix = ((p >> 3) + 1) * PITCH + (p & 7) + 1;
+                *reinterpret_cast<unsigned short*>(img + bb * board_bytes + pix * stride + c * 2) = to_bits<T>(e[k]);
+                if (++c == F) { c = 0; ++p; }
+            }
+        }
+    }
+    // pixel tile pt = 0..3: board pt >> 1, rows 4 (pt & 1) .. + 3; this lane's pixel of a tile: (py, px)
+    const int lp = PIXMAP[lane & 31];
+    const int py = lp >> 3, px = lp & 7;
+    const unsigned b_base = (py * PITCH + px) * stride + h * 16;
+    auto tile_off = [](int pt) -> unsigned { return (unsigned)((pt >> 1) * board_bytes + (pt & 1) * 4 * PITCH * stride); };
+    char* const w_base = smem + ((py + 1) * PITCH + px + 1) * stride + (64 * wave + 4 * h) * 2;
+    f32x16 acc[8];                                          // [ms * 4 + pt]
+    auto load_shift = [&](int l) {
+        const int lc = l < NL ? l : NL - 1;
+#pragma unroll
+        for (int ms = 0; ms < 2; ++ms)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const float4 s4 = *reinterpret_cast<const float4*>(a.shift + lc * 256 + 64 * wave + ms * 32 + 8 * g + 4 * h);
+#pragma unroll
+                for (int pt = 0; pt < 4; ++pt) {
+                    acc[ms * 4 + pt][4 * g + 0] = s4.x; acc[ms * 4 + pt][4 * g + 1] = s4.y;
+                    acc[ms * 4 + pt][4 * g + 2] = s4.z; acc[ms * 4 + pt][4 * g + 3] = s4.w;
+                }
+            }
+    };
+    load_shift(0);
+    // k-step n of a slice: tap = n / 4, k-step kk = n % 4 of the slice's 64 channels
+    auto kstep_off = [](int n) -> unsigned {
+        const int tap = n >> 2, kk = n & 3;
+        return (unsigned)(((tap / 3) * PITCH + (tap % 3)) * stride) + kk * 32;
+    };
+    V Bq[2][4];
+    unsigned xr[8][4][2];                                   // the residual stream of this lane's outputs, packed T
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) xr[i][g][0] = xr[i][g][1] = 0;
+    __syncthreads();                                        // the images are staged
+    // 36 k-steps: one 64-channel slice x 9 taps x 4; slot and parity are compile-time (36 % 4 == 0)
+    auto slice_steps = [&](int k0, int q) {
+#pragma unroll
+        for (int n = 0; n < 36; ++n) {
+            const int cur = n & 1, nxt = cur ^ 1, slot = n & 3;
+            // next k-step's activations (the slice's last step reads the next slice's first — or, at a layer's end, a
+            // harmless address: the layer start re-reads after the boundary's barriers)
+            const unsigned off = n + 1 < 36 ? kstep_off(n + 1) + q * 128 : (q + 1) * 128;
+#pragma unroll
+            for (int pt = 0; pt < 4; ++pt) Bq[nxt][pt] = *reinterpret_cast<const V*>(smem + b_base + tile_off(pt) + off);
+#pragma unroll
+            for (int ms = 0; ms < 2; ++ms)
+#pragma unroll
+                for (int pt = 0; pt < 4; ++pt) acc[ms * 4 + pt] = Elem<T>::mfma(Areg[slot][ms], Bq[cur][pt], acc[ms * 4 + pt]);
+            load_a(slot, k0 + n + 4);                        // this slot's fragments have been consumed: request k-step + 4
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);      // the four B reads over the first MFMA gaps
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            }
+            __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+            __builtin_amdgcn_sched_group_barrier(0x020, 2, 0);          // then the two weight loads
+        }
+    };
+    auto boundary = [&](auto kind) {
+        constexpr int KIND = decltype(kind)::value;
+#pragma unroll
+        for (int pt = 0; pt < 4; ++pt)
+#pragma unroll
+            for (int ms = 0; ms < 2; ++ms)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    float v[4];
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) v[i] = relu_keep_nan(acc[ms * 4 + pt][4 * g + i]);
+                    if (KIND == 2) {
+                        const unsigned s0 = xr[ms * 4 + pt][g][0], s1 = xr[ms * 4 + pt][g][1];
+                        v[0] += from_bits<T>((unsigned short)(s0 & 0xffff)); v[1] += from_bits<T>((unsigned short)(s0 >> 16));
+                        v[2] += from_bits<T>((unsigned short)(s1 & 0xffff)); v[3] += from_bits<T>((unsigned short)(s1 >> 16));
+                    }
+                    const unsigned p0 = pack2<T>(v[0], v[1]), p1 = pack2<T>(v[2], v[3]);
+                    if (KIND != 1) { xr[ms * 4 + pt][g][0] = p0; xr[ms * 4 + pt][g][1] = p1; }
+                    *reinterpret_cast<u32x2*>(w_base + tile_off(pt) + (ms * 32 + 8 * g) * 2) = u32x2{ p0, p1 };
+                }
+    };
+    int k0 = 0;
+    for (int l = 0; l < NL; ++l) {
+        T128_STAMP(l, 0);
+#pragma unroll
+        for (int pt = 0; pt < 4; ++pt) Bq[0][pt] = *reinterpret_cast<const V*>(smem + b_base + tile_off(pt) + kstep_off(0));
+        const int nslice = l == 0 ? 2 : 4;                  // the stem's 128 (padded) planes, the tower's 256 channels
+        for (int q = 0; q < nslice; ++q) { slice_steps(k0, q); k0 += 36; }
+        T128_STAMP(l, 1);
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");      // every wave has read what it needs of the old image
+        if (l == 0) boundary(std::integral_constant<int, 0>{});
+        else if (l & 1) boundary(std::integral_constant<int, 1>{});
+        else boundary(std::integral_constant<int, 2>{});
+        T128_STAMP(l, 3);
+        load_shift(l + 1);
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");      // the new image is complete
+        T128_STAMP(l, 2);
+    }
+#pragma unroll
+    for (int pt = 0; pt < 4; ++pt) {
+        const int b = b0 + (pt >> 1);
+        if (b >= a.B) continue;
+        const int pix = (4 * (pt & 1) + py) * 8 + px;
+        const size_t row = ((size_t)b * 64 + pix) * CH + 64 * wave;
+#pragma unroll
+        for (int ms = 0; ms < 2; ++ms)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const auto s0 = __builtin_amdgcn_permlane32_swap(xr[ms * 4 + pt][2 * j][0], xr[ms * 4 + pt][2 * j + 1][0], false, false);
+                const auto s1 = __builtin_amdgcn_permlane32_swap(xr[ms * 4 + pt][2 * j][1], xr[ms * 4 + pt][2 * j + 1][1], false, false);
+                const u32x4 o = { s0[0], s1[0], s0[1], s1[1] };
+                *reinterpret_cast<u32x4*>(a.out + row + ms * 32 + 16 * j + 8 * h) = o;
+            }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // policy_head4_kernel — the whole policy head (nn.cpp:72-80) of four boards per workgroup in one launch:
 // policyconv 1x1 (C -> 128) + pbatchnorm + ReLU, policyconv2 1x1 (128 -> 73) + bias, softmax over the board's 4 672
 // logits, policy row out.  conv4's tiling again: a wave owns one board and all output channels, so the 128-channel
@@ -1508,7 +1703,8 @@ template <typename T> static hipError_t run(const LayersArgs& L, hipStream_t s)
     // reading the fp32 planes itself.  One workgroup per four boards: worth it once that keeps most CUs busy.
     const bool fused = L.FP == 128 && L.CP == 128 && L.w4 && L.w4_off[0] != (size_t)-1 && (force == 5 || (!force && L.B >= 640));
     const bool direct = fused && (reinterpret_cast<uintptr_t>(L.in) & 15) == 0;
-    if (!direct) hipLaunchKernelGGL(planes_to_act_kernel<T>, dim3(blocks), dim3(256), 0, s, L.in, L.act_in, npix, L.F, L.FP);
+    const bool direct256 = L.FP == 128 && L.CP == 256 && L.w2b && (reinterpret_cast<uintptr_t>(L.in) & 15) == 0 && (force == 6 || (!force && L.B >= 384));
+    if (!direct && !direct256) hipLaunchKernelGGL(planes_to_act_kernel<T>, dim3(blocks), dim3(256), 0, s, L.in, L.act_in, npix, L.F, L.FP);
     unsigned short *x = L.act[0], *t = L.act[1], *u = L.act[2];
     hipError_t e;
     size_t li = 0;
@@ -1517,6 +1713,20 @@ template <typename T> static hipError_t run(const LayersArgs& L, hipStream_t s)
     auto shift = [&](int idx) { return L.shift + L.shift_off[idx]; };
     ConvArgs a;
     a.B = L.B;
+    const bool fused256 = L.FP == 128 && L.CP == 256 && L.w2b && (reinterpret_cast<uintptr_t>(L.in) & 15) == 0 && (force == 6 || (!force && L.B >= 384));
+    if (fused256) {
+        static std::atomic<bool> attr_done{ false };
+        if (!attr_done.load(std::memory_order_acquire)) {
+            if ((e = hipFuncSetAttribute(reinterpret_cast<const void*>(&tower256_kernel<T>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)) != hipSuccess) return e;
+            attr_done.store(true, std::memory_order_release);
+        }
+        Tower256Args t2;
+        t2.planes = L.in; t2.F = L.F; t2.magic = (unsigned)((0x100000000ull + L.F - 1) / L.F);
+        t2.w = L.w2b; t2.shift = shift(0); t2.out = x; t2.B = L.B; t2.R = L.R;
+        hipLaunchKernelGGL((tower256_kernel<T>), dim3((L.B + 1) / 2), dim3(256), 2 * NPIX * (256 * 2 + 16), s, t2);
+        if ((e = hipGetLastError()) != hipSuccess) return e;
+        li = 1 + 2 * (size_t)L.R;
+    }
     if (fused) {
         static std::atomic<bool> attr_done{ false };
         if (!attr_done.load(std::memory_order_acquire)) {
@@ -1531,11 +1741,11 @@ template <typename T> static hipError_t run(const LayersArgs& L, hipStream_t s)
         li = 1 + 2 * (size_t)L.R;
     }
     // stem                                                                  nn.cpp:62-65
-    if (!fused) {
+    if (!fused && !fused256) {
     a.in = L.act_in; a.w = layer(li); a.w4 = layer4(li); a.shift = shift(li); a.skip = nullptr; a.out = x; a.Ci = L.FP; a.Co = L.CP; ++li;
     if ((e = launch_conv<T, 9, 0>(a, s)) != hipSuccess) return e;
     }
-    for (int r = 0; r < (fused ? 0 : L.R); ++r) {                         // nn.cpp:26-34
+    for (int r = 0; r < ((fused || fused256) ? 0 : L.R); ++r) {           // nn.cpp:26-34
         a.in = x; a.w = layer(li); a.w4 = layer4(li); a.shift = shift(li); a.skip = nullptr; a.out = t; a.Ci = L.CP; a.Co = L.CP; ++li;
         if ((e = launch_conv<T, 9, 0>(a, s)) != hipSuccess) return e;
         a.in = t; a.w = layer(li); a.w4 = layer4(li); a.shift = shift(li); a.skip = x; a.out = u; ++li;
