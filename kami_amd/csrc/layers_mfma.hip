@@ -809,30 +809,38 @@ struct Tower256Args {
     int B, R;
 };
 
-template <typename T>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void tower256_kernel(Tower256Args a)
+// CH = 256: as described.  CH = 128 (BASELINE configs[2]'s width): a wave owns 32 channels x both boards (4 accumulators,
+// one A fragment per k-step); two 128-channel images are 65 KB, so TWO workgroups share a CU and one's boundary runs
+// under the other's MFMAs — and 2 boards per workgroup fill the chip from batch 512 on, where tower128_kernel's four
+// boards per workgroup leave half the CUs idle.
+template <typename T, int CH>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, CH == 128 ? 2 : 1))) void tower2b_kernel(Tower256Args a)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     using V = typename Elem<T>::vec8;
     const int tid = threadIdx.x, lane = tid & 63, h = lane >> 5;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    constexpr int CH = 256;
+    constexpr int MSW = CH / 128;                           // row tiles (32 output channels) per wave
+    constexpr int KSB = CH / 32 * 1024;                     // bytes of one k-step's fragments
     constexpr int stride = CH * 2 + 16;                     // 528 B per pixel: 33 16-byte slots, odd
     constexpr int board_bytes = NPIX * stride;
     const int b0 = blockIdx.x * 2;
     const int NL = 1 + 2 * a.R;
-    const int NKT = 72 + 2 * a.R * 144;                     // k-steps of the whole stack
+    constexpr int NSL = CH / 64;                            // 64-channel slices of a tower layer (the stem: 2)
+    const int NKT = 72 + 2 * a.R * 36 * NSL;                // k-steps of the whole stack
     char* img = smem;
-    // this wave's A fragments of k-step k: row tiles 2 wave, 2 wave + 1 of the step's eight
-    const char* wl = reinterpret_cast<const char*>(a.w) + (size_t)(2 * wave) * 1024 + lane * 16;
-    V Areg[4][2];
+    // this wave's A fragments of k-step k: row tiles MSW * wave .. of the step's CH / 32
+    const char* wl = reinterpret_cast<const char*>(a.w) + (size_t)(MSW * wave) * 1024 + lane * 16;
+    // requested NA k-steps ahead: 4 x 256 clocks of MFMAs at 256 channels, 8 x 128 at 128 — an L2 round trip under load
+    constexpr int NA = 4;                                    // k-steps of weight fragments in flight (8 bought nothing at 128 channels and cost the second workgroup per CU its registers)
+    V Areg[NA][MSW];
     auto load_a = [&](int slot, int k) {
-        const size_t kc = (size_t)(k < NKT ? k : NKT - 1) * CHUNKB;      // past the end: a harmless re-read
-        Areg[slot][0] = *reinterpret_cast<const V*>(wl + kc);
-        Areg[slot][1] = *reinterpret_cast<const V*>(wl + kc + 1024);
+        const size_t kc = (size_t)(k < NKT ? k : NKT - 1) * KSB;         // past the end: a harmless re-read
+#pragma unroll
+        for (int ms = 0; ms < MSW; ++ms) Areg[slot][ms] = *reinterpret_cast<const V*>(wl + kc + ms * 1024);
     };
 #pragma unroll
-    for (int j = 0; j < 4; ++j) load_a(j, j);
+    for (int j = 0; j < NA; ++j) load_a(j, j);
     {
         // fp32 planes -> T in the image (tower128_kernel's ingest, two boards): everything zeroed first (halo, planes
         // F..255 of the image: the stem only reads 0..127), then float4 pieces scattered to (pixel, plane)
@@ -871,15 +879,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     const int py = lp >> 3, px = lp & 7;
     const unsigned b_base = (py * PITCH + px) * stride + h * 16;
     auto tile_off = [](int pt) -> unsigned { return (unsigned)((pt >> 1) * board_bytes + (pt & 1) * 4 * PITCH * stride); };
-    char* const w_base = smem + ((py + 1) * PITCH + px + 1) * stride + (64 * wave + 4 * h) * 2;
-    f32x16 acc[8];                                          // [ms * 4 + pt]
+    char* const w_base = smem + ((py + 1) * PITCH + px + 1) * stride + (32 * MSW * wave + 4 * h) * 2;
+    f32x16 acc[MSW * 4];                                    // [ms * 4 + pt]
     auto load_shift = [&](int l) {
         const int lc = l < NL ? l : NL - 1;
 #pragma unroll
-        for (int ms = 0; ms < 2; ++ms)
+        for (int ms = 0; ms < MSW; ++ms)
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
-                const float4 s4 = *reinterpret_cast<const float4*>(a.shift + lc * 256 + 64 * wave + ms * 32 + 8 * g + 4 * h);
+                const float4 s4 = *reinterpret_cast<const float4*>(a.shift + lc * CH + 32 * MSW * wave + ms * 32 + 8 * g + 4 * h);
 #pragma unroll
                 for (int pt = 0; pt < 4; ++pt) {
                     acc[ms * 4 + pt][4 * g + 0] = s4.x; acc[ms * 4 + pt][4 * g + 1] = s4.y;
@@ -893,35 +901,41 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         const int tap = n >> 2, kk = n & 3;
         return (unsigned)(((tap / 3) * PITCH + (tap % 3)) * stride) + kk * 32;
     };
-    V Bq[2][4];
-    unsigned xr[8][4][2];                                   // the residual stream of this lane's outputs, packed T
+    // B fragments one k-step ahead at 256 channels (8 MFMAs = 256 clocks of cover), TWO ahead at 128 (a step is 4 MFMAs:
+    // one step of lead is an LDS round trip, and every MFMA waited for its operand)
+    constexpr int NBS = MSW == 1 ? 3 : 2;
+    V Bq[NBS][4];
+    unsigned xr[MSW * 4][4][2];                                 // the residual stream of this lane's outputs, packed T
 #pragma unroll
-    for (int i = 0; i < 8; ++i)
+    for (int i = 0; i < MSW * 4; ++i)
 #pragma unroll
         for (int g = 0; g < 4; ++g) xr[i][g][0] = xr[i][g][1] = 0;
     __syncthreads();                                        // the images are staged
-    // 36 k-steps: one 64-channel slice x 9 taps x 4; slot and parity are compile-time (36 % 4 == 0)
-    auto slice_steps = [&](int k0, int q) {
+    // 36 k-steps: one 64-channel slice x 9 taps x 4; register-set parity and the A slot are compile-time: 36 % 4 == 0,
+    // and with 8 slots the slice's first slot is 0 or 4 (`s0`, an integral_constant)
+    auto slice_steps = [&](int k0, int q, auto s0) {
+        constexpr int S0 = decltype(s0)::value;
 #pragma unroll
         for (int n = 0; n < 36; ++n) {
-            const int cur = n & 1, nxt = cur ^ 1, slot = n & 3;
-            // next k-step's activations (the slice's last step reads the next slice's first — or, at a layer's end, a
+            const int cur = n % NBS, nxt = (n + NBS - 1) % NBS, slot = (n + S0) & (NA - 1);
+            // activations of k-step n + NBS - 1 (past the slice's end: the next slice's first — or, at a layer's end, a
             // harmless address: the layer start re-reads after the boundary's barriers)
-            const unsigned off = n + 1 < 36 ? kstep_off(n + 1) + q * 128 : (q + 1) * 128;
+            const int m = n + NBS - 1;
+            const unsigned off = m < 36 ? kstep_off(m) + q * 128 : kstep_off(m - 36) + (q + 1) * 128;
 #pragma unroll
             for (int pt = 0; pt < 4; ++pt) Bq[nxt][pt] = *reinterpret_cast<const V*>(smem + b_base + tile_off(pt) + off);
 #pragma unroll
-            for (int ms = 0; ms < 2; ++ms)
+            for (int ms = 0; ms < MSW; ++ms)
 #pragma unroll
                 for (int pt = 0; pt < 4; ++pt) acc[ms * 4 + pt] = Elem<T>::mfma(Areg[slot][ms], Bq[cur][pt], acc[ms * 4 + pt]);
-            load_a(slot, k0 + n + 4);                        // this slot's fragments have been consumed: request k-step + 4
+            load_a(slot, k0 + n + NA);                       // this slot's fragments have been consumed: request k-step + NA
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);      // the four B reads over the first MFMA gaps
                 __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
             }
-            __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
-            __builtin_amdgcn_sched_group_barrier(0x020, 2, 0);          // then the two weight loads
+            if (MSW == 2) __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+            __builtin_amdgcn_sched_group_barrier(0x020, MSW, 0);        // then the weight loads
         }
     };
     auto boundary = [&](auto kind) {
@@ -929,7 +943,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 #pragma unroll
         for (int pt = 0; pt < 4; ++pt)
 #pragma unroll
-            for (int ms = 0; ms < 2; ++ms)
+            for (int ms = 0; ms < MSW; ++ms)
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
                     float v[4];
@@ -949,9 +963,16 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     for (int l = 0; l < NL; ++l) {
         T128_STAMP(l, 0);
 #pragma unroll
-        for (int pt = 0; pt < 4; ++pt) Bq[0][pt] = *reinterpret_cast<const V*>(smem + b_base + tile_off(pt) + kstep_off(0));
-        const int nslice = l == 0 ? 2 : 4;                  // the stem's 128 (padded) planes, the tower's 256 channels
-        for (int q = 0; q < nslice; ++q) { slice_steps(k0, q); k0 += 36; }
+        for (int j = 0; j < NBS - 1; ++j)
+#pragma unroll
+            for (int pt = 0; pt < 4; ++pt) Bq[j][pt] = *reinterpret_cast<const V*>(smem + b_base + tile_off(pt) + kstep_off(j));
+        const int nslice = l == 0 ? 2 : NSL;                // the stem's 128 (padded) planes, the tower's CH channels
+        for (int q = 0; q < nslice; ++q) {
+            if constexpr (NA == 4) slice_steps(k0, q, std::integral_constant<int, 0>{});
+            else if ((k0 & 7) == 0) slice_steps(k0, q, std::integral_constant<int, 0>{});
+            else slice_steps(k0, q, std::integral_constant<int, 4>{});
+            k0 += 36;
+        }
         T128_STAMP(l, 1);
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");      // every wave has read what it needs of the old image
         if (l == 0) boundary(std::integral_constant<int, 0>{});
@@ -967,9 +988,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         const int b = b0 + (pt >> 1);
         if (b >= a.B) continue;
         const int pix = (4 * (pt & 1) + py) * 8 + px;
-        const size_t row = ((size_t)b * 64 + pix) * CH + 64 * wave;
+        const size_t row = ((size_t)b * 64 + pix) * CH + 32 * MSW * wave;
 #pragma unroll
-        for (int ms = 0; ms < 2; ++ms)
+        for (int ms = 0; ms < MSW; ++ms)
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
                 const auto s0 = __builtin_amdgcn_permlane32_swap(xr[ms * 4 + pt][2 * j][0], xr[ms * 4 + pt][2 * j + 1][0], false, false);
@@ -1701,9 +1722,11 @@ template <typename T> static hipError_t run(const LayersArgs& L, hipStream_t s)
     static const int force = getenv("KAMI_WIDE_VARIANT") ? atoi(getenv("KAMI_WIDE_VARIANT")) : 0;
     // 128 planes (padded) and 128 filters: the whole 3x3 stack in one launch, activations on chip (tower128_kernel),
     // reading the fp32 planes itself.  One workgroup per four boards: worth it once that keeps most CUs busy.
-    const bool fused = L.FP == 128 && L.CP == 128 && L.w4 && L.w4_off[0] != (size_t)-1 && (force == 5 || (!force && L.B >= 640));
+    const bool fused = L.FP == 128 && L.CP == 128 && L.w4 && L.w4_off[0] != (size_t)-1 && force != 6 && (force == 5 || (!force && L.B >= 640));
     const bool direct = fused && (reinterpret_cast<uintptr_t>(L.in) & 15) == 0;
-    const bool direct256 = L.FP == 128 && L.CP == 256 && L.w2b && (reinterpret_cast<uintptr_t>(L.in) & 15) == 0 && (force == 6 || (!force && L.B >= 384));
+    const bool direct256 = (reinterpret_cast<uintptr_t>(L.in) & 15) == 0 && L.FP == 128 &&
+                           ((L.CP == 256 && L.w2b && (force == 6 || (!force && L.B >= 384))) ||
+                            (L.CP == 128 && L.w4 && L.w4_off[0] != (size_t)-1 && (force == 6 || (!force && L.B >= 256 && !fused))));
     if (!direct && !direct256) hipLaunchKernelGGL(planes_to_act_kernel<T>, dim3(blocks), dim3(256), 0, s, L.in, L.act_in, npix, L.F, L.FP);
     unsigned short *x = L.act[0], *t = L.act[1], *u = L.act[2];
     hipError_t e;
@@ -1713,21 +1736,27 @@ template <typename T> static hipError_t run(const LayersArgs& L, hipStream_t s)
     auto shift = [&](int idx) { return L.shift + L.shift_off[idx]; };
     ConvArgs a;
     a.B = L.B;
-    const bool fused256 = L.FP == 128 && L.CP == 256 && L.w2b && (reinterpret_cast<uintptr_t>(L.in) & 15) == 0 && (force == 6 || (!force && L.B >= 384));
+    // two boards per workgroup, waves own output channels (tower2b_kernel): 256 filters from batch 384 on; 128 filters
+    // for the batches where tower128_kernel's four boards per workgroup do not fill the chip (KAMI_WIDE_VARIANT=6 forces it)
+    const bool aligned = (reinterpret_cast<uintptr_t>(L.in) & 15) == 0;
+    const bool fused256 = aligned && L.FP == 128 && ((L.CP == 256 && L.w2b && (force == 6 || (!force && L.B >= 384))) ||
+                                                      (L.CP == 128 && L.w4 && L.w4_off[0] != (size_t)-1 && (force == 6 || (!force && L.B >= 256 && !fused))));
     if (fused256) {
         static std::atomic<bool> attr_done{ false };
         if (!attr_done.load(std::memory_order_acquire)) {
-            if ((e = hipFuncSetAttribute(reinterpret_cast<const void*>(&tower256_kernel<T>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)) != hipSuccess) return e;
+            if ((e = hipFuncSetAttribute(reinterpret_cast<const void*>(&tower2b_kernel<T, 256>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)) != hipSuccess) return e;
+            if ((e = hipFuncSetAttribute(reinterpret_cast<const void*>(&tower2b_kernel<T, 128>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)) != hipSuccess) return e;
             attr_done.store(true, std::memory_order_release);
         }
         Tower256Args t2;
         t2.planes = L.in; t2.F = L.F; t2.magic = (unsigned)((0x100000000ull + L.F - 1) / L.F);
-        t2.w = L.w2b; t2.shift = shift(0); t2.out = x; t2.B = L.B; t2.R = L.R;
-        hipLaunchKernelGGL((tower256_kernel<T>), dim3((L.B + 1) / 2), dim3(256), 2 * NPIX * (256 * 2 + 16), s, t2);
+        t2.w = L.CP == 256 ? L.w2b : layer4(0); t2.shift = shift(0); t2.out = x; t2.B = L.B; t2.R = L.R;
+        if (L.CP == 256) hipLaunchKernelGGL((tower2b_kernel<T, 256>), dim3((L.B + 1) / 2), dim3(256), 2 * NPIX * (256 * 2 + 16), s, t2);
+        else hipLaunchKernelGGL((tower2b_kernel<T, 128>), dim3((L.B + 1) / 2), dim3(256), 2 * NPIX * (128 * 2 + 16), s, t2);
         if ((e = hipGetLastError()) != hipSuccess) return e;
         li = 1 + 2 * (size_t)L.R;
     }
-    if (fused) {
+    if (fused && !fused256) {
         static std::atomic<bool> attr_done{ false };
         if (!attr_done.load(std::memory_order_acquire)) {
             if ((e = hipFuncSetAttribute(reinterpret_cast<const void*>(&tower128_kernel<T>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)) != hipSuccess) return e;

@@ -5,7 +5,7 @@ sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
 from kami_amd import NN, weights as W, _lib as L
 L.LIB_PATH = os.path.abspath(os.environ.get("KAMI_AB_LIB", "kami_amd/csrc/build/libkamihip_diag.so"))
 lib = L.load(); raw = C.CDLL(L.LIB_PATH)
-F, Cc, R, B, dt = (119, 256, 20, 512, "f16") if len(sys.argv) > 1 and sys.argv[1] == "256" else (119, 128, 10, 1024, "bf16")
+F, Cc, R, B, dt = (119, 256, 20, 512, "f16") if len(sys.argv) > 1 and sys.argv[1] == "256" else (119, 128, 10, int(sys.argv[2]) if len(sys.argv) > 2 else 1024, "bf16")
 nn = NN(8, 8, F, 4672, filters=Cc, residuals=R, dtype=dt)
 nn.load_weights(W.random_weights(F, Cc, R, seed=1), 1)
 x = np.random.default_rng(0).random((B, 8, 8, F), dtype=np.float32)

@@ -1,7 +1,8 @@
 """Per-forward time of the wide-net configurations, once per kernel variant (KAMI_WIDE_VARIANT is read once per process:
 this script re-runs itself per variant).  0 = the launcher's own choice; 1/2/3 = conv_mfma_kernel with that many
 workgroups per CU; 4 = conv4_mfma_kernel (four boards x 128 output channels per workgroup), per layer;
-5 = tower128_kernel (128 filters: the whole 3x3 stack in one launch)."""
+5 = tower128_kernel (128 filters: the whole 3x3 stack in one launch, four boards per workgroup); 6 = tower2b_kernel
+(128 / 256 filters: the whole stack, two boards per workgroup, waves own output channels)."""
 import sys, os, subprocess, ctypes as C
 sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
 CASES = ((119, 128, 10, 1024, "bf16"), (119, 128, 10, 512, "bf16"), (119, 128, 10, 2048, "bf16"),
@@ -26,5 +27,5 @@ if len(sys.argv) > 1:
         for p in (d_in, d_p, d_v): lib.kh_dev_free(nn.handle, p)
         nn.close()
 else:
-    for v in (0, 5, 4, 3):
+    for v in (0, 6, 5, 3):
         subprocess.run([sys.executable, __file__, str(v)], env=dict(os.environ, KAMI_WIDE_VARIANT=str(v)), check=False)
