@@ -1736,7 +1736,7 @@ template <typename T> static hipError_t run(const LayersArgs& L, hipStream_t s)
     auto shift = [&](int idx) { return L.shift + L.shift_off[idx]; };
     ConvArgs a;
     a.B = L.B;
-    // two boards per workgroup, waves own output channels (tower2b_kernel): 256 filters from batch 384 on; 128 filters
+    // two boards per workgroup, waves own output channels (tower2b_kernel): 256 filters from batch 256 on; 128 filters
     // for the batches where tower128_kernel's four boards per workgroup do not fill the chip (KAMI_WIDE_VARIANT=6 forces it)
     const bool aligned = (reinterpret_cast<uintptr_t>(L.in) & 15) == 0;
     const bool fused256 = aligned && L.FP == 128 && ((L.CP == 256 && L.w2b && (force == 6 || (!force && L.B >= 256))) ||

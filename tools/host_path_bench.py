@@ -2,7 +2,6 @@
 import sys, os, time, threading, numpy as np
 sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
 from kami_amd import NN, weights as W, _lib as L
-from oracle import pyoracle as ko
 
 def rate(fn, n, iters=30):
     fn(); fn()
@@ -27,8 +26,10 @@ for F in (119, 30):
             print(f"F={F} B={B}: kh_infer {sum(res):,.0f} evals/s ({T} threads)")
     if F == 30:
         B = 512
-        start = "rnbqkbnr/pppppppp/8/8/8/8/PPPPPPPP/RNBQKBNR w KQkq - 0 1"
-        boards = ko.boards_from_fens([start] * B, [0] * B)
+        rng = np.random.default_rng(1)                       # random occupancies: the encoder's cost does not depend on them
+        boards = np.zeros(B, dtype=L.BOARD_DTYPE)
+        boards["piece_occ"] = rng.integers(0, 2**63, (B, 6), dtype=np.uint64); boards["color_occ"] = rng.integers(0, 2**63, (B, 2), dtype=np.uint64)
+        boards["ply"] = rng.integers(0, 300, B); boards["ctm"] = rng.integers(0, 2, B); boards["castle_rights"] = rng.integers(0, 16, B)
         offs = (np.arange(B + 1) * 20).astype(np.int32)
         acts = np.tile(np.array([584, 657, 730, 803, 876] * 4, np.int32), B)
         print(f"F=30 B=512: kh_encode_infer {rate(lambda: nn.encode_infer(boards), B):,.0f} evals/s")

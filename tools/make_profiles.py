@@ -118,12 +118,12 @@ for Cc, Rr, B, dt in ((128, 10, 1024, "bf16"), (256, 20, 256, "f16"), (256, 20, 
         continue
     write_stats(rows, f"{tag}_wide_{Rr}x{Cc}_b{B}_{dt}_kernel_stats.csv")
     dominant = max(rows, key=lambda r: float(r["TotalDurationNs"]))
-    key = "tower128_kernel" if "tower128" in dominant["Name"] else ("conv4_mfma_kernel" if "conv4" in dominant["Name"] else "conv_mfma_kernel")
+    key = next((k for k in ("tower128_kernel", "tower2b_kernel", "conv4_mfma_kernel") if k in dominant["Name"]), "conv_mfma_kernel")
     ctr = {}
     for d in (f"pmcf_{wtag}", f"pmcw_{wtag}", f"pmcs_{wtag}"):
         ctr.update(counters(d, key))
     calls = {r["Name"]: int(r["Calls"]) for r in rows}
-    once = [int(r["Calls"]) for r in rows if "policy_head4" in r["Name"] or "softmax" in r["Name"] or "tower128" in r["Name"]]
+    once = [int(r["Calls"]) for r in rows if any(k in r["Name"] for k in ("policy_head4", "softmax", "tower128", "tower2b"))]
     fwd = min(once) if once else 1                         # kernels that run once per forward
     per_forward_ns = sum(float(r["TotalDurationNs"]) for r in rows if "fillBuffer" not in r["Name"] and "copyBuffer" not in r["Name"]) / fwd
     flops = (1152 * 119 * Cc + 2304 * Rr * Cc * Cc + 16512 * Cc + 1228800) * B
@@ -134,8 +134,9 @@ for Cc, Rr, B, dt in ((128, 10, 1024, "bf16"), (256, 20, 256, "f16"), (256, 20, 
                                  "share_of_kernel_time": float(dominant["TotalDurationNs"]) / sum(float(r["TotalDurationNs"]) for r in rows)},
              "counters_of_dominant_kernel_per_dispatch": ctr}
     # algorithmic HBM bytes of the dominant kernel's dispatch
-    if key == "tower128_kernel":
-        alg = B * 64 * 128 * 2 * 2                              # padded planes in (T), residual stream out (T)
+    if key in ("tower128_kernel", "tower2b_kernel"):
+        # fp32 planes in, residual stream out (T), every layer's packed weights once
+        alg = B * 64 * 119 * 4 + B * 64 * Cc * 2 + (9 * 128 * Cc + Rr * 2 * 9 * Cc * Cc) * 2
     elif key == "conv4_mfma_kernel":
         alg = B * 64 * Cc * 2 * 3                               # in, skip, out
     else:
@@ -150,7 +151,7 @@ for Cc, Rr, B, dt in ((128, 10, 1024, "bf16"), (256, 20, 256, "f16"), (256, 20, 
 if wide:
     json.dump({"round": rnd, "kernel_source_sha16": sha, "configs": wide}, open(f"{dst}/{tag}_wide_summary.json", "w"), indent=1)
 
-for name in ("wide_variants", "host_path_bench", "selfplay_bench", "train_bench", "train_bench_valu", "encode_bench"):
+for name in ("wide_variants", "host_path_bench", "pinned_probe", "selfplay_bench", "train_bench", "train_bench_valu", "encode_bench"):
     p = f"{src}/{name}.txt"
     if os.path.exists(p) and os.path.getsize(p):
         shutil.copy(p, f"{dst}/{tag}_{name}.txt")

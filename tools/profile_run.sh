@@ -27,6 +27,7 @@ for cfg in "128 10 1024 bf16" "256 20 256 f16" "256 20 2048 f16"; do
 done
 timeout -k 10 300 python tools/wide_variants.py > $O/wide_variants.txt 2>&1
 timeout -k 10 200 python tools/host_path_bench.py > $O/host_path_bench.txt 2>&1
+timeout -k 10 200 python tools/pinned_probe.py > $O/pinned_probe.txt 2>&1
 timeout -k 10 300 python tools/selfplay_bench.py > $O/selfplay_bench.txt 2>&1
 timeout -k 10 300 python tools/train_bench.py > $O/train_bench.txt 2>&1
 KAMI_TRAIN_VALU=1 timeout -k 10 300 python tools/train_bench.py > $O/train_bench_valu.txt 2>&1
