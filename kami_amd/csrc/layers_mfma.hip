@@ -830,14 +830,18 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, CH == 12
     const int NKT = 72 + 2 * a.R * 36 * NSL;                // k-steps of the whole stack
     char* img = smem;
     // this wave's A fragments of k-step k: row tiles MSW * wave .. of the step's CH / 32
-    const char* wl = reinterpret_cast<const char*>(a.w) + (size_t)(MSW * wave) * 1024 + lane * 16;
+    // (a scalar base per k-step + one 32-bit lane offset: the SGPR-base form of global_load, no 64-bit vector address math)
+    const char* wl = reinterpret_cast<const char*>(a.w) + (size_t)(MSW * wave) * 1024;
+    const unsigned wlane = lane * 16;
     // requested NA k-steps ahead: 4 x 256 clocks of MFMAs at 256 channels, 8 x 128 at 128 — an L2 round trip under load
     constexpr int NA = 4;                                    // k-steps of weight fragments in flight (8 bought nothing at 128 channels and cost the second workgroup per CU its registers)
     V Areg[NA][MSW];
     auto load_a = [&](int slot, int k) {
         const size_t kc = (size_t)(k < NKT ? k : NKT - 1) * KSB;         // past the end: a harmless re-read
+        unsigned vo = wlane;
+        asm volatile("" : "+v"(vo));                         // keeps the lane offset out of a hoisted 64-bit vector base
 #pragma unroll
-        for (int ms = 0; ms < MSW; ++ms) Areg[slot][ms] = *reinterpret_cast<const V*>(wl + kc + ms * 1024);
+        for (int ms = 0; ms < MSW; ++ms) Areg[slot][ms] = *reinterpret_cast<const V*>(wl + kc + ms * 1024 + vo);
     };
 #pragma unroll
     for (int j = 0; j < NA; ++j) load_a(j, j);
