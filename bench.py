@@ -219,6 +219,31 @@ def variant_legs(torch, lib, NN, W, L, device, prewarm):
     return out
 
 
+def pcie_probe():
+    """What the host link of this box moves between page-locked host memory and HBM: each direction alone, and both at once
+    (kh_infer needs both: planes in while policies go out)."""
+    import torch
+    n = 128 << 20
+    h_in = torch.empty(n, dtype=torch.uint8).pin_memory(); h_out = torch.empty(n, dtype=torch.uint8).pin_memory()
+    d_in = torch.empty(n, dtype=torch.uint8, device="cuda"); d_out = torch.empty(n, dtype=torch.uint8, device="cuda")
+    s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+
+    def timed(h2d, d2h, reps=8):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            if h2d:
+                with torch.cuda.stream(s1): d_in.copy_(h_in, non_blocking=True)
+            if d2h:
+                with torch.cuda.stream(s2): h_out.copy_(d_out, non_blocking=True)
+        s1.synchronize(); s2.synchronize()
+        return n * reps / (time.perf_counter() - t0) / 1e9
+    timed(True, True, 2)
+    a, b, c = timed(True, False), timed(False, True), timed(True, True)
+    return {"call": "host link probe", "workload": "128 MiB copies between page-locked host memory and HBM", "h2d_GBps": round(a, 1), "d2h_GBps": round(b, 1),
+            "h2d_GBps_both_directions": round(c, 1), "d2h_GBps_both_directions": round(c, 1)}
+
+
 def end_to_end_legs(NN, W, L, device):
     """The host-buffer ABI, PCIe included (what an unmodified kami sees through NN::infer, and what this repository's
     search sends): pageable caller buffers, synchronous calls, evaluations per wall second."""
@@ -245,6 +270,11 @@ def end_to_end_legs(NN, W, L, device):
         return sum(res)
 
     B, F = 512, 119
+    link = pcie_probe()
+    bound = min(link["h2d_GBps_both_directions"] * 1e9 / (64 * F * 4), link["d2h_GBps_both_directions"] * 1e9 / (4672 * 4 + 4))
+    link["kh_infer_bound"] = (f"{bound / 1e6:.2f} M leaf-evals/s on THIS box's link with both directions busy ({64 * F * 4} B in, {4672 * 4 + 4} B out "
+                              "per evaluation); SURVEY 7's 2.07 M/s assumed 63 GB/s per direction")
+    out.append(link)
     nn = NN(8, 8, F, 4672, filters=64, residuals=6, dtype="bf16", device=device)
     nn.load_weights(W.random_weights(F, 64, 6, seed=1), 1)
 
@@ -256,7 +286,7 @@ def end_to_end_legs(NN, W, L, device):
         out.append({"call": "kh_infer", "workload": f"{B} x ({F}x8x8) fp32 planes in, full [4672] policy + value out per call, 6x64 bf16 "
                                                     "(the legacy float ABI of NN::infer, nn.cpp:155-187)",
                     "threads": T, "value": round(threaded(make_infer, B, T), 1), "unit": "leaf-evals/s",
-                    "pcie_bound": "2.07 M/s at 63 GB/s per direction (30 464 B in, 18 692 B out per evaluation; SURVEY 7)"})
+                    "pcie_bound_leaf_evals_per_s": round(bound, 1)})
     pinned = []
 
     def make_infer_pinned(i):

@@ -1,18 +1,24 @@
-// layers_mfma.hip — bf16 / f16 forward pass for WIDE nets (65..256 filters): one MFMA kernel
-// launch per layer, activations as T [B][64][C] (channels-last) in HBM / L2.
+// layers_mfma.hip — bf16 / f16 forward pass for WIDE nets (65..256 filters) and the exact-fp32 path, on the matrix
+// cores.  The whole-network kernel (tower_mfma.hip) is specialised for <= 64 filters; from 128 filters up a 3x3 layer is
+// >= 4x the work, one layer's weights (up to 1.2 MB) and two boards' activations no longer fit a CU the same way, and
+// the tiling is chosen per width and batch (run<T>() at the end of this file; DESIGN.md 5.3 has the anatomy, the
+// measurements and what was tried and dropped):
 //
-// The whole-network kernel (tower_mfma.hip) is specialised for <= 64 filters, where a launch
-// per layer would cost more than the arithmetic.  From 128 filters up a 3x3 layer is >= 4x the
-// work (19 GFLOP per layer at 256 filters x 256 boards), launch boundaries stop mattering, the
-// activations of two boards no longer fit LDS twice, and the weights of one layer (up to 1.2 MB)
-// are better read once per 64-channel output block than streamed through every CU: so this
-// path is a plain per-layer implicit GEMM.  It covers BASELINE configs 3 and 5 (10x128, 20x256)
-// (0.23 / 0.30 of the bf16 roofline: DESIGN.md 5.3 has the in-kernel anatomy and what was tried).
+//   conv_mfma_kernel      one launch per layer, workgroup = 2 boards x 64 output channels, weights through an LDS ring
+//                         fed by LDS-DMA, activations T [B][64][C] (channels-last) in HBM / L2.  Any width 65..256.
+//   conv4_mfma_kernel     per layer, 4 boards x 128 channels, a wave owns one board (0.75 LDS reads per MFMA).
+//   tower128_kernel       128 filters: the whole 3x3 stack in ONE launch, conv4's tiling, wave-local layer boundaries
+//                         (no barrier, no HBM between layers); reads the fp32 planes itself.  BASELINE configs[2].
+//   tower2b_kernel<T,CH>  256 (and 128) filters: the whole stack in one launch, 2 boards per workgroup, waves own output
+//                         channels, weights global -> registers (no ring), two barriers per boundary.  configs[4]'s net.
+//   policy_head4_kernel   policy 1x1 convs + softmax + value head of four boards per workgroup in one launch.
+//   conv_f32_kernel / conv_f32_small_kernel   v_mfma_f32_32x32x2_f32 (an exact fp32 fmaf chain): dtype = f32 inference
+//                         and the trainer's forward / data gradient (train.hip).
 //
-// Kernel: workgroup = 2 boards x 64 output channels.  The two boards' input images (all Ci
-// channels, zero halo, pixel stride 2*Ci + 16 bytes, row pitch 12: same conflict-free geometry as
-// the tower kernel) are staged in LDS once; each of the 4 waves computes 64 channels x 32 pixels,
-// B fragments from LDS, A fragments (pre-packed weights) through a 4-slot LDS ring fed by LDS-DMA.
+// All bf16 / f16 variants walk the reduction in the same order (64-channel slices, taps, k-steps) with the same fp32
+// epilogue, so they agree BIT FOR BIT and the launcher may pick per call (tests/test_gpu_parity.py compares them).
+// Geometry shared with the tower kernel: input images with a zero halo, pixel stride 2*Ci + 16 bytes, row pitch 12
+// (conflict-free ds_read_b128 groups for all nine taps).
 #include "kh_internal.h"
 
 #include <algorithm>
