@@ -52,10 +52,10 @@ inline std::map<std::string, Member> zip_members(const std::vector<uint8_t>& z)
     if (count == 0xffff || cdoff == 0xffffffffu) {                       // zip64
         if (eocd < 20 || rd32(&z[eocd - 20]) != 0x07064b50) bad("zip64 locator missing");
         const uint64_t e64 = rd64(&z[eocd - 20 + 8]);
-        if (e64 + 56 > n || rd32(&z[e64]) != 0x06064b50) bad("zip64 end record missing");
+        if (e64 > n || n - e64 < 56 || rd32(&z[e64]) != 0x06064b50) bad("zip64 end record missing");
         count = rd64(&z[e64 + 32]); cdsize = rd64(&z[e64 + 40]); cdoff = rd64(&z[e64 + 48]);
     }
-    if (cdoff + cdsize > n) bad("central directory out of range");
+    if (cdoff > n || cdsize > n - cdoff) bad("central directory out of range");      // (no sums of untrusted 64-bit fields)
     std::map<std::string, Member> out;
     size_t p = cdoff;
     for (uint64_t i = 0; i < count; ++i) {
@@ -76,10 +76,10 @@ inline std::map<std::string, Member> zip_members(const std::vector<uint8_t>& z)
             }
             x += 4 + len;
         }
-        if (lho + 30 > n || rd32(&z[lho]) != 0x04034b50) bad("bad local header for " + name);
+        if (lho > n || n - lho < 30 || rd32(&z[lho]) != 0x04034b50) bad("bad local header for " + name);
         m.offset = lho + 30 + rd16(&z[lho + 26]) + rd16(&z[lho + 28]);
         m.size = m.method == 0 ? usize : csize;
-        if (m.offset + m.size > n) bad("member " + name + " out of range");
+        if (m.offset > n || m.size > n - m.offset) bad("member " + name + " out of range");
         out[name] = m;
         p += 46 + nl + xl + cl;
     }
@@ -246,24 +246,31 @@ inline Checkpoint read_checkpoint(const std::string& path)
     Checkpoint ck;
     struct Walker {
         const std::vector<uint8_t>& z; std::map<std::string, Member>& members; const std::string& root; Checkpoint& ck;
-        void walk(const Value& obj, const std::string& prefix)
+        void walk(const Value& obj, const std::string& prefix, int depth = 0)
         {
+            if (depth > 32) bad("module tree too deep (a cycle?)");        // a memo reference can make a state contain its own object
             for (auto& kv : obj.dict) {
                 if (kv.first->kind != Value::STR) bad("attribute name is not a string");
                 const std::string name = prefix + kv.first->s;
                 const Value& v = *kv.second;
-                if (v.kind == Value::OBJECT) walk(v, name + ".");
+                if (v.kind == Value::OBJECT) walk(v, name + ".", depth + 1);
                 else if (v.kind == Value::TENSOR) {
                     if (name.size() > 19 && name.compare(name.size() - 19, 19, "num_batches_tracked") == 0) continue;   // int64 counters nn.cpp never reads
                     if (v.s != "FloatStorage") bad(name + " is not an fp32 tensor");
                     auto it = members.find(root + "/data/" + v.s2);
                     if (it == members.end()) bad("storage " + v.s2 + " missing");
                     if (it->second.method != 0) bad("tensor data is compressed");
-                    int64_t numel = 1;
-                    for (int64_t s : v.size) { if (s < 0) bad("negative size"); numel *= s; }
-                    int64_t want = 1;                                   // contiguous tensors only (what module.save writes)
-                    for (size_t k = v.size.size(); k-- > 0;) { if (v.size[k] != 1 && v.stride[k] != want) bad(name + " is not contiguous"); want *= v.size[k]; }
-                    if ((uint64_t)(v.offset + numel) * 4 > it->second.size || v.offset < 0) bad(name + " exceeds its storage");
+                    if (v.stride.size() != v.size.size()) bad(name + ": sizes and strides differ in rank");
+                    const uint64_t cap = it->second.size / 4;          // elements the storage holds: every product stays below it
+                    uint64_t numel = 1;
+                    for (int64_t s : v.size) {
+                        if (s < 0) bad("negative size");
+                        if (s != 0 && numel > cap / (uint64_t)s) bad(name + " exceeds its storage");
+                        numel *= (uint64_t)s;
+                    }
+                    uint64_t want = 1;                                  // contiguous tensors only (what module.save writes)
+                    for (size_t k = v.size.size(); k-- > 0;) { if (v.size[k] != 1 && (uint64_t)v.stride[k] != want) bad(name + " is not contiguous"); want *= (uint64_t)v.size[k]; }
+                    if (v.offset < 0 || (uint64_t)v.offset > cap || numel > cap - (uint64_t)v.offset) bad(name + " exceeds its storage");
                     Tensor t;
                     t.shape = v.size;
                     t.data.resize((size_t)numel);

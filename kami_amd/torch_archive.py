@@ -167,28 +167,38 @@ def read_archive(path: str) -> Tuple[Dict[str, np.ndarray], Dict[str, object]]:
         attrs: Dict[str, object] = {}
         storages: Dict[str, bytes] = {}
 
-        def walk(obj: _Object, prefix: str):
+        def walk(obj: _Object, prefix: str, depth: int = 0):
+            if depth > 32:                                   # a memo reference can make a state contain its own object
+                raise ArchiveError("module tree too deep (a cycle?)")
             for k, v in obj.state.items():
                 name = prefix + str(k)
                 if isinstance(v, _Object):
-                    walk(v, name + ".")
+                    walk(v, name + ".", depth + 1)
                 elif isinstance(v, _TensorRef):
                     member = f"{root}/data/{v.key}"
                     if v.key not in storages:
+                        if member not in names:
+                            raise ArchiveError(f"storage {v.key} missing")
                         info = z.getinfo(member)
                         if info.compress_type != zipfile.ZIP_STORED:
                             raise ArchiveError(f"{member}: tensor data is compressed")
                         storages[v.key] = z.read(member)
                     raw = np.frombuffer(storages[v.key], dtype=v.dtype)
-                    if raw.size < v.numel:
-                        raise ArchiveError(f"{member}: {raw.size} elements, the pickle says {v.numel}")
-                    numel = int(np.prod(v.size)) if v.size else 1
-                    contiguous = tuple(int(np.prod(v.size[j + 1:])) for j in range(len(v.size)))
-                    if any(s != c and d != 1 for s, c, d in zip(v.stride, contiguous, v.size)):
-                        t = np.lib.stride_tricks.as_strided(raw[v.offset:], v.size, tuple(s * raw.itemsize for s in v.stride)).copy()
-                    else:
-                        t = raw[v.offset:v.offset + numel].reshape(v.size).copy()
-                    tensors[name] = t
+                    # sizes, strides and offset come from the file: contiguous tensors only (what module.save writes), every
+                    # element inside the storage — nothing here may index memory by an unchecked number
+                    if len(v.stride) != len(v.size) or any(d < 0 for d in v.size) or v.offset < 0:
+                        raise ArchiveError(f"{name}: malformed size / stride / offset")
+                    numel = 1
+                    for d in v.size:
+                        numel *= d
+                    want = 1
+                    for d, st in zip(reversed(v.size), reversed(v.stride)):
+                        if d != 1 and st != want:
+                            raise ArchiveError(f"{name} is not contiguous")
+                        want *= d
+                    if v.offset + numel > raw.size:
+                        raise ArchiveError(f"{name} exceeds its storage ({raw.size} elements)")
+                    tensors[name] = raw[v.offset:v.offset + numel].reshape(v.size).copy()
                 elif prefix == "":
                     attrs[name] = v
 

@@ -94,3 +94,59 @@ def test_checkpoint_reader_refuses_what_it_does_not_know(tmp_path):
         read_checkpoint(str(evil))
     with pytest.raises(TA.ArchiveError, match="refusing to call"):
         TA.load_reference_checkpoint(str(evil))
+
+
+def _hostile_archive(path, pkl, storage=b"\x00" * 16):
+    with zipfile.ZipFile(path, "w", zipfile.ZIP_STORED) as z:
+        z.writestr("m/data.pkl", pkl)
+        z.writestr("m/data/0", storage)
+        z.writestr("m/version", b"3\n")
+
+
+def _tensor_pickle(size, stride, offset=0):
+    """data.pkl of a module with ONE fp32 tensor attribute 'w' over storage '0' (4 elements), sizes / strides as given."""
+    def num(v):
+        return b"\x8a\x08" + int(v).to_bytes(8, "little", signed=True)
+
+    def tup(vals):
+        return b"(" + b"".join(num(v) for v in vals) + b"t"
+    s = lambda t: b"X" + len(t).to_bytes(4, "little") + t
+    storage = b"(" + s(b"storage") + b"ctorch\nFloatStorage\n" + s(b"0") + s(b"cpu") + b"K\x04" + b"tQ"
+    tensor = (b"ctorch._utils\n_rebuild_tensor_v2\n(" + storage + num(offset) + tup(size) + tup(stride) + b"\x89" +
+              b"ccollections\nOrderedDict\n)R" + b"tR")
+    return b"\x80\x02c__torch__.M\nM\n)\x81}(" + s(b"w") + tensor + b"ub."
+
+
+@pytest.mark.parametrize("size,stride,offset,what", [
+    ((1 << 40,), (1,), 0, "exceeds its storage"),            # more elements than the storage holds
+    ((1 << 33, 1 << 33), (1 << 33, 1), 0, "exceeds"),        # a product that overflows 64 bits
+    ((2, 2), (1,), 0, "stride|rank"),                        # rank mismatch
+    ((2, 2), (1 << 20, 1), 0, "contiguous"),                 # a stride that would index far outside the storage
+    ((4,), (1,), 3, "exceeds its storage"),                  # offset + numel past the end
+    ((4,), (1,), -1, "exceeds|malformed"),
+    ((-4,), (1,), 0, "negative|malformed"),
+])
+def test_checkpoint_readers_bound_every_number_from_the_file(tmp_path, size, stride, offset, what):
+    """Sizes, strides and offsets of a tensor come from the file: both readers refuse anything that would read outside
+    the tensor's storage (the file is untrusted input)."""
+    from kami_amd import KamiError, torch_archive as TA
+    from kami_amd.nn import read_checkpoint
+    p = str(tmp_path / "hostile.pt")
+    _hostile_archive(p, _tensor_pickle(size, stride, offset))
+    with pytest.raises(KamiError, match=what):
+        read_checkpoint(p)
+    with pytest.raises(TA.ArchiveError, match=what):
+        TA.read_archive(p)
+
+
+def test_checkpoint_readers_survive_a_module_that_contains_itself(tmp_path):
+    from kami_amd import KamiError, torch_archive as TA
+    from kami_amd.nn import read_checkpoint
+    s = lambda t: b"X" + len(t).to_bytes(4, "little") + t
+    pkl = b"\x80\x02c__torch__.M\nM\n)\x81q\x00}(" + s(b"me") + b"h\x00ub."
+    p = str(tmp_path / "cycle.pt")
+    _hostile_archive(p, pkl)
+    with pytest.raises(KamiError, match="too deep"):
+        read_checkpoint(p)
+    with pytest.raises(TA.ArchiveError, match="too deep"):
+        TA.read_archive(p)
