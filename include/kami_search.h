@@ -56,9 +56,10 @@ typedef struct ks_pool_config {
     int32_t alpha_cutoff;
     int32_t draw_value_pct;     /* "draw_value_pct" (selfplay.cpp:71)                                          */
     uint32_t seed;
-    int32_t pipeline;           /* 1: each worker keeps TWO halves of its trees in flight through the engine's queue
-                                   (kh_submit_encode_infer_legal / kh_wait): one half on the device while the other is
-                                   expanded and selected; 0: one blocking call per round (the reference's schedule)    */
+    int32_t pipeline;           /* 1 or 2: each worker keeps TWO sets of its trees in flight through the engine's queue
+                                   (kh_submit_encode_infer_legal / kh_wait): one set on the device while the other is
+                                   expanded and selected; 3, 4: that many sets (more, smaller launches in flight);
+                                   0: one blocking call per round (the reference's schedule)                            */
     int32_t coalesce_target;    /* pipeline: kh_set_coalesce(engine, target, wait): positions per launch to wait for   */
     int32_t coalesce_wait_us;   /*           ... and for how long at most                                               */
     int32_t reserved[1];

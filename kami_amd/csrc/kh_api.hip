@@ -902,8 +902,8 @@ constexpr int CO_ROWS = 1024;                   // boards per coalesced launch (
 constexpr int CO_ACTS = CO_ROWS * 48;           // legal actions per coalesced launch
 constexpr int CO_SMALL_LEGAL = 512;             // a submission larger than this takes the direct path
 constexpr int CO_SMALL_PLANES = 128;
-constexpr int CO_BUFFERS = 4;
-constexpr int CO_LANES = 2;
+constexpr int CO_BUFFERS = 6;
+constexpr int CO_LANES = 4;                     // at most; two run unless KAMI_CO_LANES says otherwise
 
 struct CoTicket {
     uint32_t serial = 0;
@@ -1093,7 +1093,9 @@ Coalescer* co_get(kh_engine* e)
         c->e = e;
         c->trace = getenv("KAMI_CO_TRACE") != nullptr;
         if (getenv("KAMI_WAIT_SPIN_US")) c->spin_us = std::max(0, atoi(getenv("KAMI_WAIT_SPIN_US")));
-        for (auto& l : c->lanes) l = std::thread(co_lane, c);
+        int nl = 2;
+        if (getenv("KAMI_CO_LANES")) nl = std::min(CO_LANES, std::max(1, atoi(getenv("KAMI_CO_LANES"))));
+        for (int i = 0; i < nl; ++i) c->lanes[i] = std::thread(co_lane, c);
         e->co = c;
     }
     return e->co;

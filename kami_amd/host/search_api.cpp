@@ -4,6 +4,7 @@
 #include "kami_search.h"
 #include "mcts.h"
 
+#include <algorithm>
 #include <atomic>
 #include <chrono>
 #include <cstdarg>
@@ -303,13 +304,19 @@ struct LeafSet {
 void worker(ks_pool* p, int g0, int g1, int64_t target_evals, double deadline_s, std::chrono::steady_clock::time_point t0)
 {
     const int L = p->cfg.leaves_per_tree > 0 ? p->cfg.leaves_per_tree : 1;
-    // pipeline: the worker's trees in two halves, each half one submission to the engine's queue — while one half is
-    // on the device the other is expanded and selected (kh_submit_encode_infer_legal / kh_wait); otherwise one blocking
+    // pipeline: the worker's trees in two (or more) sets, each set one submission to the engine's queue — while one set is
+    // on the device the others are expanded and selected (kh_submit_encode_infer_legal / kh_wait); otherwise one blocking
     // call per round over all of its trees (the reference's schedule, selfplay.cpp:196)
-    const bool pipeline = p->cfg.pipeline != 0 && g1 - g0 >= 2;
-    LeafSet sets[2];
-    sets[0].g0 = g0; sets[0].g1 = pipeline ? g0 + (g1 - g0) / 2 : g1;
-    sets[1].g0 = sets[0].g1; sets[1].g1 = g1;
+    // (pipeline = 1 means two sets; 2..4 that many: more launches in flight, each smaller)
+    constexpr int MAX_SETS = 4;
+    const int want_sets = p->cfg.pipeline <= 0 ? 1 : std::min(MAX_SETS, std::max(2, p->cfg.pipeline));
+    const int nsets = std::max(1, std::min(want_sets, g1 - g0));
+    const bool pipeline = nsets >= 2;
+    LeafSet sets[MAX_SETS];
+    for (int k = 0; k < MAX_SETS; ++k) {
+        sets[k].g0 = g0 + (int)((int64_t)(g1 - g0) * std::min(k, nsets) / nsets);
+        sets[k].g1 = g0 + (int)((int64_t)(g1 - g0) * std::min(k + 1, nsets) / nsets);
+    }
     auto now = [] { return std::chrono::steady_clock::now(); };
     auto stop = [&] {
         return p->evals.load() >= target_evals || std::chrono::duration<double>(now() - t0).count() > deadline_s;
@@ -334,7 +341,7 @@ void worker(ks_pool* p, int g0, int g1, int64_t target_evals, double deadline_s,
                 s.expand(p);
             }
         } else {
-            for (int k = 0;; k ^= 1) {
+            for (int k = 0;; k = (k + 1) % nsets) {
                 LeafSet& s = sets[k];
                 if (s.in_flight) finish(s);
                 if (stop()) break;

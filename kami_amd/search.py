@@ -162,7 +162,7 @@ class Pool:
         self.lib = load()
         self.nn = nn                      # keep the engine alive
         cfg = PoolConfig(games, threads, nodes, leaves_per_tree, cpuct, noise_weight, alpha[0], alpha[1], alpha[2],
-                         alpha_cutoff, draw_value_pct, seed, int(pipeline), coalesce_target, coalesce_wait_us)
+                         alpha_cutoff, draw_value_pct, seed, int(pipeline), coalesce_target, coalesce_wait_us)   # pipeline: False / True (two sets) / 2..4 sets
         self.h = C.c_void_p()
         if self.lib.ks_pool_create(nn.handle, C.byref(cfg), C.byref(self.h)):
             raise RuntimeError(self.lib.ks_last_error().decode())

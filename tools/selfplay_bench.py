@@ -13,14 +13,17 @@ CASES = [  # games, threads, leaves/tree, visits/move, pipeline, coalesce target
     (256, 14, 2, 800, 1, 512, 200), (256, 14, 2, 800, 1, 512, 80),               # 512 positions in flight, queue + 2 launch lanes
     (256, 14, 4, 800, 1, 512, 200), (256, 14, 4, 800, 1, 512, 80), (256, 8, 4, 800, 1, 512, 80),   # 1024 in flight: two batch-512 evaluations
     (256, 14, 8, 800, 1, 512, 80),
+    (256, 14, 2, 800, 3, 512, 80), (256, 14, 2, 800, 4, 512, 80), (256, 14, 2, 800, 4, 256, 40), (256, 14, 4, 800, 3, 512, 80), (256, 14, 4, 800, 4, 512, 80),   # three / four sets per worker
     # many trees, one leaf each (the reference's schedule, more games)
     (8192, 16, 1, 64, 0, 0, 0), (8192, 14, 1, 64, 1, 1024, 100), (4096, 14, 2, 64, 1, 1024, 100),
 ]
-if len(sys.argv) > 1:
+if len(sys.argv) > 2:
+    CASES = CASES[int(sys.argv[1]):int(sys.argv[2])]
+elif len(sys.argv) > 1:
     CASES = CASES[:int(sys.argv[1])]
 for games, threads, leaves, nodes, pipe, target, wait in CASES:
     nn.set_coalesce(0, 0)
-    pool = S.Pool(nn, games=games, threads=threads, nodes=nodes, leaves_per_tree=leaves, seed=1, pipeline=bool(pipe),
+    pool = S.Pool(nn, games=games, threads=threads, nodes=nodes, leaves_per_tree=leaves, seed=1, pipeline=int(pipe),
                   coalesce_target=target, coalesce_wait_us=wait)
     pool.run(min_evals=20000, max_seconds=10.0)          # warm-up
     s0 = pool.run(min_evals=0, max_seconds=0.0)
@@ -30,8 +33,8 @@ for games, threads, leaves, nodes, pipe, target, wait in CASES:
     l1, r1 = nn.coalesce_stats()
     de, dt = st.evals - e0, st.seconds - t0
     launch = f"engine launches of {(r1 - r0) / max(1, l1 - l0):6.1f} positions" if l1 > l0 else f"engine calls of {de / max(1, st.batches - b0):6.1f} positions"
-    print(f"games {games:5d} threads {threads:2d} leaves/tree {leaves} visits {nodes:3d} {'pipe' if pipe else 'sync'} target {target:4d}/{wait:3d}us: "
+    print(f"games {games:5d} threads {threads:2d} leaves/tree {leaves} visits {nodes:3d} {('pipe%d' % max(2, pipe)) if pipe else 'sync '} target {target:4d}/{wait:3d}us: "
           f"{de / dt:12,.0f} leaf-evals/s  {launch}  worker submissions of {de / max(1, st.batches - b0):6.1f}  "
-          f"waiting on the engine {100 * (st.engine_seconds - g0) / (dt * threads * (2 if pipe else 1)):4.1f} % "
+          f"waiting on the engine {100 * (st.engine_seconds - g0) / (dt * threads * (max(2, pipe) if pipe else 1)):4.1f} % "
           f"moves {st.moves} games finished {st.games_finished}", flush=True)
     del pool
