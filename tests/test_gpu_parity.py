@@ -609,19 +609,20 @@ def test_weight_swap_while_threads_infer():
     assert nn.get_generation() == 61 and all(len(s) == 2 for s in seen)      # every thread saw both generations
 
 
-def test_selfplay_pool_pipelined_through_the_queue():
-    """The pool with two halves of every worker's trees in flight (kh_submit_encode_infer_legal / kh_wait) and the
-    engine merging the workers' submissions: BASELINE configs[1]'s shape (256 games, two leaves per tree = 512 positions
-    in flight), four workers; launches hold several workers' leaves."""
+@pytest.mark.parametrize("sets", [2, 3])
+def test_selfplay_pool_pipelined_through_the_queue(sets):
+    """The pool with two halves (or three thirds) of every worker's trees in flight (kh_submit_encode_infer_legal /
+    kh_wait) and the engine merging the workers' submissions: BASELINE configs[1]'s shape (256 games, two leaves per
+    tree = 512 positions in flight), four workers; launches hold several workers' leaves."""
     from kami_amd import search as S
     F, C, R = 30, 64, 6
     nn = NN(8, 8, F, 4672, filters=C, residuals=R, dtype="bf16", value_mode=L.KH_VALUE_PER_SAMPLE0)
     nn.load_weights(W.random_weights(F, C, R, seed=5, peaky=5.0), 1)
-    pool = S.Pool(nn, games=256, threads=4, nodes=64, leaves_per_tree=2, seed=12, pipeline=True, coalesce_target=512, coalesce_wait_us=300)
+    pool = S.Pool(nn, games=256, threads=4, nodes=64, leaves_per_tree=2, seed=12, pipeline=sets, coalesce_target=512, coalesce_wait_us=300)
     st = pool.run(min_evals=200000, max_seconds=20.0)
     assert st.evals >= 200000 and st.moves > st.evals // 80
     launches, rows = nn.coalesce_stats()
-    assert rows == st.evals and rows / launches > 64 * 1.5, (launches, rows)     # a worker's half is 64 leaves
+    assert rows == st.evals and rows / launches > 128 / sets * 1.5, (launches, rows)     # one submission of a worker is 128 / sets leaves
     recs = pool.drain()
     assert st.records == len(recs) and st.games_finished == st.white_wins + st.black_wins + st.draws
     for r in recs[:100]:
