@@ -1191,8 +1191,8 @@ int co_submit(kh_engine* e, int kind, const kh_board* boards, const float* plane
     b->rows += batch; b->nact += nact;
     b->tickets.push_back(t);
     ++b->copying;
+    b->last = std::chrono::steady_clock::now();           // (under the lock: the lanes read it there)
     lk.unlock();
-    b->last = std::chrono::steady_clock::now();
     // this caller's rows into the merge buffers (every caller copies its own, in parallel)
     if (kind == 0) {
         memcpy(b->boards + t->row0, boards, (size_t)batch * sizeof(kh_board));
