@@ -78,6 +78,7 @@ __global__ __launch_bounds__(256) void gather_legal_kernel(const float* __restri
         for (int b = blockIdx.x * blockDim.x + threadIdx.x; b < B; b += gridDim.x * blockDim.x) values[b] = vfull[(size_t)b * vstride];
         if (blockIdx.x == 0 && threadIdx.x < 4) flags_out[threadIdx.x] = flags_in[threadIdx.x];
     }
+    if (!offsets) return;                       // values + flags only (the zero-copy small-batch path of kh_infer)
     for (int b = blockIdx.x * wpb + (threadIdx.x >> 6); b < B; b += gridDim.x * wpb) {
         const int lo = offsets[b], hi = offsets[b + 1];
         const float* p = policy + (size_t)b * KH_PSIZE;

@@ -514,6 +514,8 @@ struct kh_engine {
     kh_config cfg;
     int num_cus = 256;
     bool f32_simple = false;     // KAMI_F32_SIMPLE=1: dtype f32 always runs forward_simple.hip
+    int small_max = 128;         // kh_infer up to this batch AND up to 768 KB of planes takes the zero-copy path
+                                 // (KAMI_SMALL_MAX; 0: never): measured 1.6x per thread at batch 16, even at 2 MB of planes
     std::mutex wmu;
     std::shared_ptr<Weights> weights;
     std::mutex smu;
@@ -779,6 +781,40 @@ int infer_host_pinned(kh_engine* e, const Weights& W, Slot& s, const float* inpu
     return KH_OK;
 }
 
+// kh_infer at SMALL batches (kami's default selfplay_batch is 16): a call is latency, not bandwidth — four runtime
+// copies out of / into pageable memory and their synchronisation cost more than the kernel.  So: the planes are copied by
+// the CPU into the slot's page-locked block, the kernel reads them from there and writes the policy rows into the
+// page-locked output block ITSELF (as the queue's launches do with records and priors), a second tiny launch puts the
+// values and NaN flags behind them, completion is polled, and the CPU copies the rows out.  No copy engine, one wait.
+int infer_host_small(kh_engine* e, const Weights& W, Slot& s, const float* input, int batch, float* policy, float* value)
+{
+    const size_t B = batch, F = e->cfg.features;
+    const size_t in_bytes = B * 64 * F * 4, pol_bytes = B * KH_PSIZE * 4;
+    const size_t o_val = (pol_bytes + 15) & ~(size_t)15, o_flags = o_val + ((B * 4 + 15) & ~(size_t)15);
+    if (s.hin.ensure(in_bytes) || s.hout.ensure(o_flags + 16)) return KH_ERR_HIP;
+    memcpy(s.hin.p, input, in_bytes);
+    int rc = forward_tower(e, W, s, static_cast<const float*>(s.hin.p), batch, reinterpret_cast<float*>(s.hout.at(0)), s.vfull.as<float>(), nullptr);
+    if (rc) return rc;
+    hipStream_t st = s.stream;
+    const int vstride = e->cfg.value_mode == KH_VALUE_REFERENCE_FLAT ? 1 : KH_VALUE_WIDTH;     // nn.cpp:186 / the value column
+    int* fl = reinterpret_cast<int*>(s.hout.at(o_flags));
+    kh::launch_gather_legal(nullptr, nullptr, nullptr, nullptr, batch, st, s.vfull.as<float>(), vstride, reinterpret_cast<float*>(s.hout.at(o_val)),
+                            s.flags.as<int>(), fl);
+    HIPCHK(hipGetLastError());
+    for (int k = 0;; ++k) {
+        const hipError_t q = hipStreamQuery(st);
+        if (q == hipSuccess) break;
+        if (q != hipErrorNotReady) return fail(KH_ERR_HIP, "hipStreamQuery failed: %s", hipGetErrorString(q));
+        if ((k & 15) == 15) sched_yield();
+    }
+    memcpy(policy, s.hout.at(0), pol_bytes);                        // nn.cpp:173,185
+    memcpy(value, s.hout.at(o_val), B * 4);
+    if (fl[0] | fl[1]) s.flags_clean = false;
+    if (fl[0]) return fail(KH_ERR_NAN_POLICY, "inference policy output contains NaN");   // nn.cpp:176-177
+    if (fl[1]) return fail(KH_ERR_NAN_VALUE, "inference value output contains NaN");     // nn.cpp:179-180
+    return KH_OK;
+}
+
 int infer_host(kh_engine* e, const float* input, const kh_board* boards, int batch,
                float* policy, float* value, float* value_full, float* logits, const LegalIO* legal = nullptr)
 {
@@ -805,6 +841,9 @@ int infer_host(kh_engine* e, const float* input, const kh_board* boards, int bat
     if (input && policy && value && !legal && !logits && !value_full && e->cfg.dtype != KH_F32 && W->tw_ok &&
         (reinterpret_cast<uintptr_t>(input) & 15) == 0 && is_pinned(e, input, B * 64 * F * 4) && is_pinned(e, policy, B * KH_PSIZE * 4))
         return infer_host_pinned(e, *W, s, input, batch, policy, value);
+    if (input && policy && value && !legal && !logits && !value_full && e->cfg.dtype != KH_F32 && W->tw_ok && batch <= e->small_max &&
+        B * 64 * F * 4 <= 768 * 1024)
+        return infer_host_small(e, *W, s, input, batch, policy, value);
     const float* d_in;
     const bool fused = boards && fused_ingest(e, *W) && !logits;
     // The search's call (records or planes in, legal priors + one value per position out): everything
@@ -1298,6 +1337,7 @@ int kh_create(const kh_config* cfg, kh_engine** out)
     e->cfg = *cfg;
     e->num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     e->f32_simple = getenv("KAMI_F32_SIMPLE") && atoi(getenv("KAMI_F32_SIMPLE")) != 0;
+    if (getenv("KAMI_SMALL_MAX")) e->small_max = std::max(0, atoi(getenv("KAMI_SMALL_MAX")));
     *out = e;
     return KH_OK;
 }

@@ -12,7 +12,7 @@ def rate(fn, n, iters=30):
 for F in (119, 30):
     nn = NN(8, 8, F, 4672, filters=64, residuals=6, dtype="bf16")
     nn.load_weights(W.random_weights(F, 64, 6, seed=1), 1)
-    for B in (16, 512):
+    for B in (16, 64, 512):
         x = np.random.default_rng(0).random((B, 8, 8, F), dtype=np.float32)
         pol = np.empty((B, 4672), np.float32); val = np.empty(B, np.float32)
         print(f"F={F} B={B}: kh_infer {rate(lambda: nn.infer(x, B, pol, val), B):,.0f} evals/s (1 thread)")
