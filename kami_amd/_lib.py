@@ -97,4 +97,4 @@ def load():
 
 
 def last_error() -> str:
-    return (load().kh_last_error() or b"").decode()
+    return (load().kh_last_error() or b"").decode("utf-8", "replace")      # (a message may quote bytes of a malformed file)

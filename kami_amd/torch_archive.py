@@ -15,6 +15,7 @@ from __future__ import annotations
 
 import struct
 import zipfile
+from zlib import error as zlib_error
 from typing import Dict, Tuple
 
 import numpy as np
@@ -81,7 +82,7 @@ def _unpickle(data: bytes):
             i += 1
         elif op == 0x63:                                 # GLOBAL 'module name'
             e1 = data.index(b"\n", i); e2 = data.index(b"\n", e1 + 1)
-            stack.append(_Global(data[i:e1].decode(), data[e1 + 1:e2].decode())); i = e2 + 1
+            stack.append(_Global(data[i:e1].decode("latin-1"), data[e1 + 1:e2].decode("latin-1"))); i = e2 + 1
         elif op == 0x71: memo[data[i]] = stack[-1]; i += 1                                  # BINPUT
         elif op == 0x72: memo[struct.unpack_from("<I", data, i)[0]] = stack[-1]; i += 4     # LONG_BINPUT
         elif op == 0x68: stack.append(memo[data[i]]); i += 1                                # BINGET
@@ -92,7 +93,7 @@ def _unpickle(data: bytes):
         elif op == 0x28: stack.append(_MARK)                                               # MARK
         elif op == 0x58:                                                                   # BINUNICODE
             ln = struct.unpack_from("<I", data, i)[0]; i += 4
-            stack.append(data[i:i + ln].decode()); i += ln
+            stack.append(data[i:i + ln].decode("utf-8", "replace")); i += ln
         elif op == 0x4b: stack.append(data[i]); i += 1                                      # BININT1
         elif op == 0x4d: stack.append(struct.unpack_from("<H", data, i)[0]); i += 2         # BININT2
         elif op == 0x4a: stack.append(struct.unpack_from("<i", data, i)[0]); i += 4         # BININT
@@ -153,7 +154,18 @@ def _unpickle(data: bytes):
 
 
 def read_archive(path: str) -> Tuple[Dict[str, np.ndarray], Dict[str, object]]:
-    """-> (tensors by dotted name, other attributes such as 'generation')."""
+    """-> (tensors by dotted name, other attributes such as 'generation').  Whatever a malformed file trips over inside
+    zipfile / struct / numpy comes out as ArchiveError."""
+    try:
+        return _read_archive(path)
+    except ArchiveError:
+        raise
+    except (zipfile.BadZipFile, zlib_error, struct.error, IndexError, KeyError, ValueError, EOFError, OverflowError,
+            NotImplementedError, TypeError, AttributeError, RecursionError) as e:
+        raise ArchiveError(f"malformed archive: {type(e).__name__}: {e}") from None
+
+
+def _read_archive(path: str) -> Tuple[Dict[str, np.ndarray], Dict[str, object]]:
     with zipfile.ZipFile(path) as z:
         names = z.namelist()
         pkl = [n for n in names if n.endswith("/data.pkl") and n.count("/") == 1]

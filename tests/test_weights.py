@@ -150,3 +150,36 @@ def test_checkpoint_readers_survive_a_module_that_contains_itself(tmp_path):
         read_checkpoint(p)
     with pytest.raises(TA.ArchiveError, match="too deep"):
         TA.read_archive(p)
+
+
+def test_checkpoint_readers_survive_mutated_archives(tmp_path):
+    """Seeded byte mutations of the reference-written archive (biased to the pickle and the zip directory, some
+    truncated): both readers either return a blob or raise their error — no crash, nothing else."""
+    import random
+    from kami_amd import KamiError, torch_archive as TA
+    from kami_amd.nn import read_checkpoint
+    src = open(CKPT, "rb").read()
+    with zipfile.ZipFile(CKPT) as z:
+        info = z.getinfo("ref_checkpoint_f30_c8_r1/data.pkl")
+    pk0, pk1 = info.header_offset, info.header_offset + 30 + len(info.filename) + info.file_size + 64
+    rnd = random.Random(20240607)
+    p = str(tmp_path / "m.pt")
+    accepted = refused = 0
+    for _ in range(400):
+        b = bytearray(src)
+        region = rnd.choice(("pkl", "dir", "any"))
+        for _ in range(rnd.choice((1, 1, 2, 4, 16))):
+            i = rnd.randrange(pk0, pk1) if region == "pkl" else rnd.randrange(len(b) - 6000, len(b)) if region == "dir" else rnd.randrange(len(b))
+            b[i] = rnd.randrange(256)
+        if rnd.random() < 0.1:
+            b = b[:rnd.randrange(len(b))]
+        open(p, "wb").write(b)
+        try:
+            read_checkpoint(p); accepted += 1
+        except KamiError:
+            refused += 1
+        try:
+            TA.load_reference_checkpoint(p)
+        except TA.ArchiveError:
+            pass
+    assert refused > 100 and accepted > 20
