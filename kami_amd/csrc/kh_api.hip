@@ -1502,7 +1502,13 @@ int kh_checkpoint_read(const char* path, int* features, int* filters, int* resid
     if (got == sizeof hdr && hdr[0] == 0x574d414b /* "KAMW" */) {
         F = hdr[1]; C = hdr[2]; R = hdr[3]; gen = hdr[4];
         if (F < 1 || F > 4096 || C < 1 || C > 1024 || R < 0 || R > 256) { fclose(f); return fail(KH_ERR_INVALID, "%s: bad header", path); }
-        data.resize(kh_weight_count(F, C, R));
+        // the header's numbers come from the file: size the buffer only once the file is known to hold that many floats
+        const size_t need = kh_weight_count(F, C, R);
+        fseek(f, 0, SEEK_END);
+        const long fsz = ftell(f);
+        fseek(f, (long)sizeof hdr, SEEK_SET);
+        if (fsz < 0 || ((size_t)fsz - sizeof hdr) / 4 < need) { fclose(f); return fail(KH_ERR_INVALID, "%s: truncated", path); }
+        data.resize(need);
         const size_t n = fread(data.data(), 4, data.size(), f);
         fclose(f);
         if (n != data.size()) return fail(KH_ERR_INVALID, "%s: truncated", path);

@@ -116,6 +116,8 @@ def load(path: str):
         magic, F, C, R, gen, _, _, _ = struct.unpack("<8i", hdr)
         if magic != MAGIC:
             raise ValueError("not a kami weight blob")
+        if not (1 <= F <= 4096 and 1 <= C <= 1024 and 0 <= R <= 256):         # the engine's own limits (kh_checkpoint_read)
+            raise ValueError("weight file header out of range")
         blob = np.frombuffer(f.read(), dtype="<f4").copy()
     if blob.size != weight_count(F, C, R):
         raise ValueError("weight file size does not match its header")

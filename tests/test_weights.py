@@ -183,3 +183,20 @@ def test_checkpoint_readers_survive_mutated_archives(tmp_path):
         except TA.ArchiveError:
             pass
     assert refused > 100 and accepted > 20
+
+
+def test_weight_container_header_is_bounded_before_anything_is_sized(tmp_path):
+    """A weight file whose header claims a huge network (or a negative one) is refused at once by both loaders: nothing
+    is allocated or looped over by the header's numbers."""
+    import struct, time
+    from kami_amd import KamiError
+    from kami_amd.nn import read_checkpoint
+    for F, C, R in ((4096, 1024, 256), (30, 8, 2_000_000_000), (-1, 8, 1), (30, 0, 1)):
+        p = str(tmp_path / "h.bin")
+        open(p, "wb").write(struct.pack("<8i", W.MAGIC, F, C, R, 1, 0, 0, 0) + b"\x00" * 64)
+        t0 = time.time()
+        with pytest.raises(KamiError):
+            read_checkpoint(p)
+        with pytest.raises(ValueError):
+            W.load(p)
+        assert time.time() - t0 < 1.0
