@@ -336,6 +336,8 @@ struct Position {
             ++f;
         }
         if (i >= fen.size()) return false;
+        // move generation asks for each side's king square: a board without one is refused here
+        if (!(p.pc[KING] & p.col[WHITE]) || !(p.pc[KING] & p.col[BLACK])) return false;
         ++i;
         p.ctm = fen[i] == 'b' ? BLACK : WHITE;
         i += 2;
@@ -346,13 +348,20 @@ struct Position {
             if (fen[i] == 'q') p.castle |= CASTLE_BQ;
         }
         ++i;
-        if (i < fen.size() && fen[i] != '-') { p.ep = (int8_t)((fen[i] - 'a') + 8 * (fen[i + 1] - '1')); i += 2; }
-        else ++i;
+        if (i < fen.size() && fen[i] != '-') {
+            // an en-passant square is a file letter and rank 3 or 6; anything else is not a FEN
+            if (i + 1 >= fen.size() || fen[i] < 'a' || fen[i] > 'h' || (fen[i + 1] != '3' && fen[i + 1] != '6')) return false;
+            p.ep = (int8_t)((fen[i] - 'a') + 8 * (fen[i + 1] - '1'));
+            i += 2;
+        } else ++i;
         if (i < fen.size()) {
             p.halfmove = std::atoi(fen.c_str() + i);
             const size_t sp = fen.find(' ', i + 1);
             if (sp != std::string::npos) p.fullmove = std::atoi(fen.c_str() + sp + 1);
         }
+        // the side that has just moved may not have left its king attacked: otherwise the king could be captured and the
+        // next position would have none
+        if (p.attacked(p.king_sq(!p.ctm), p.ctm)) return false;
         return true;
     }
 };

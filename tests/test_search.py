@@ -162,3 +162,22 @@ def test_env_record_is_what_observe_reads():
     for f in ("piece_occ", "color_occ", "ply", "halfmove_clock", "ctm", "castle_rights"):
         assert np.array_equal(mine[f], want[f]), f
     assert np.array_equal(ko.observe(mine), ko.observe(want))
+
+
+@pytest.mark.parametrize("fen", [
+    "rnbq1bnr/pppppppp/8/8/8/8/PPPPPPPP/RNBQKBNR w KQkq - 0 1",       # no black king
+    "rnbqkbnr/pppppppp/8/8/8/8/PPPPPPPP/RNBQ1BNR w KQkq - 0 1",       # no white king
+    "rnbqkbnr/pppp1ppp/8/4Q3/8/8/PPPP1PPP/RNB1KBNR w KQkq - 0 1",     # white to move while black's king is attacked
+    "rnbqkbnr/ppp1p1pp/8/3pPp2/8/8/PPPP1PPP/RNBQKBNR w KQkq f9 0 3",  # en-passant square off the board
+    "rnbqkbnr/ppp1p1pp/8/3pPp2/8/8/PPPP1PPP/RNBQKBNR w KQkq z6 0 3",
+    "rnbqkbnr/pppppppp/8/8/8/8/PPPPPPPP/RNBQKBNR",                    # board only
+    "", "k", "8/8/8/8/8/8/8/8 w - - 0 1",
+])
+def test_positions_the_rules_cannot_play_are_refused(fen):
+    """Move generation asks for both kings' squares and assumes the side that just moved is not in check (the reference's
+    neocortex assumes the same): the FEN reader refuses anything else instead of running on it (found by fuzzing the
+    parser under ASan / UBSan: __builtin_ctzll(0))."""
+    with pytest.raises(ValueError):
+        S.fen_actions(fen)
+    with pytest.raises(ValueError):
+        S.perft(fen, 1)
