@@ -211,6 +211,10 @@ int  kh_wait(kh_engine* e, int64_t ticket);
  * submission and no longer than max_wait_us / 8 after its latest one (the burst has ended) — for callers that know how
  * many positions they keep in flight (the self-play pool). */
 int  kh_set_coalesce(kh_engine* e, int target_batch, int max_wait_us);
+/* With a target set: a batch also goes as soon as it holds `callers` submissions (0, the default: rule off) — for a pool
+ * whose every worker submits once per round, the round is complete then, whatever its size (terminal leaves need no
+ * evaluation, so rounds rarely reach the target exactly). */
+int  kh_set_coalesce_callers(kh_engine* e, int callers);
 /* launches made by the queue so far and the positions they held (mean coalesced batch = rows / launches) */
 int  kh_coalesce_stats(kh_engine* e, int64_t* launches, int64_t* rows);
 

@@ -526,7 +526,7 @@ struct kh_engine {
     Coalescer* co = nullptr;          // submit / wait queue (created on first use)
     std::mutex co_mu;
     std::atomic<int> small_calls{ 0 };       // synchronous small-batch calls currently inside the engine
-    std::atomic<int> co_target{ 0 }, co_wait_us{ 0 };
+    std::atomic<int> co_target{ 0 }, co_wait_us{ 0 }, co_callers{ 0 };
     // kh_train's workspace, staging, stream and recorded step: kept from call to call (selfplay.cpp:266 trains again and
     // again with the same batch size and learning rate; allocating 0.1-2 GB and instantiating a ~270-node graph per
     // call cost more than a dozen SGD steps)
@@ -1086,7 +1086,8 @@ void co_lane(Coalescer* c)
             // target mode: wait for `target` rows — but no longer than wait_us after the batch's first submission, and
             // not once the burst of submissions has ended (nothing added for wait_us / 8: callers that keep a fixed
             // number of positions in flight rarely hit the target exactly — terminal leaves need no evaluation)
-            bool ready = b.full || target <= 0 || b.rows >= target;
+            const int callers = e->co_callers.load();
+            bool ready = b.full || target <= 0 || b.rows >= target || (callers > 0 && (int)b.tickets.size() >= callers);
             if (!ready) {
                 const auto due = std::min(b.first + std::chrono::microseconds(wait_us), b.last + std::chrono::microseconds(wait_us / 8 + 1));
                 if (std::chrono::steady_clock::now() >= due) ready = true;
@@ -1640,6 +1641,14 @@ int kh_set_coalesce(kh_engine* e, int target_batch, int max_wait_us)
         return fail(KH_ERR_INVALID, "target_batch in [0, %d], max_wait_us in [0, 1000000]", CO_ROWS);
     e->co_target = target_batch;
     e->co_wait_us = max_wait_us;
+    if (e->co) e->co->cv_lane.notify_all();
+    return KH_OK;
+}
+
+int kh_set_coalesce_callers(kh_engine* e, int callers)
+{
+    if (!e || callers < 0 || callers > KH_MAX_OUTSTANDING) return fail(KH_ERR_INVALID, "callers in [0, %d]", KH_MAX_OUTSTANDING);
+    e->co_callers = callers;
     if (e->co) e->co->cv_lane.notify_all();
     return KH_OK;
 }

@@ -380,6 +380,8 @@ int ks_pool_create(kh_engine* engine, const ks_pool_config* cfg, ks_pool** out)
         delete p;
         return fail("%s", kh_last_error());
     }
+    // every worker submits one set per round: a launch that holds a submission of each is a whole round
+    if (cfg->pipeline && cfg->coalesce_target > 0) (void)kh_set_coalesce_callers(engine, std::min(cfg->threads, cfg->games));
     p->games.resize((size_t)cfg->games);
     for (int i = 0; i < cfg->games; ++i) {
         MCTSConfig mc;
@@ -428,6 +430,10 @@ int64_t ks_pool_drain_records(ks_pool* p, ks_record* out, int64_t cap)
     return n;
 }
 
-void ks_pool_destroy(ks_pool* p) { delete p; }
+void ks_pool_destroy(ks_pool* p)
+{
+    if (p && p->cfg.pipeline && p->cfg.coalesce_target > 0) (void)kh_set_coalesce_callers(p->engine, 0);
+    delete p;
+}
 
 }  // extern "C"

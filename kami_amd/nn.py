@@ -248,6 +248,11 @@ class NN:
     def set_coalesce(self, target_batch: int = 0, max_wait_us: int = 0) -> None:
         _chk(self._lib.kh_set_coalesce(self._h, target_batch, max_wait_us))
 
+
+    def set_coalesce_callers(self, callers: int):
+        """With a target set: a batch also goes once it holds `callers` submissions (0: off)."""
+        _chk(self._lib.kh_set_coalesce_callers(self._h, callers))
+
     def coalesce_stats(self):
         """(launches made by the queue, positions they held)"""
         a, b = C.c_int64(), C.c_int64()

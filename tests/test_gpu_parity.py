@@ -486,6 +486,35 @@ def test_submit_never_blocks_on_the_callers_own_tickets():
     assert np.array_equal(p, want[0])
 
 
+def test_a_launch_goes_when_every_caller_has_submitted():
+    """kh_set_coalesce_callers: with a target the round would otherwise wait out (target 512, half a second), a batch
+    that holds a submission of each of the 3 callers goes at once; with the rule off the same round waits for the
+    quiet period."""
+    import time
+    F, C, R = 30, 64, 2
+    nn = NN(8, 8, F, 4672, filters=C, residuals=R, dtype="bf16")
+    nn.load_weights(W.random_weights(F, C, R, seed=3, peaky=10.0), 1)
+    x = np.random.default_rng(0).random((8, 8, 8, F), dtype=np.float32)
+    want = nn.infer(x)
+    nn.submit_infer(x).wait()                                    # the queue's threads and buffers exist
+    nn.set_coalesce(512, 480000)                                 # quiet period 60 ms
+
+    def round_of_three():
+        t0 = time.perf_counter()
+        for t in [nn.submit_infer(x) for _ in range(3)]:
+            p, v = t.wait()
+            assert np.array_equal(p, want[0]) and np.array_equal(v, want[1])
+        return time.perf_counter() - t0
+    slow = round_of_three()
+    nn.set_coalesce_callers(3)
+    fast = min(round_of_three() for _ in range(3))
+    nn.set_coalesce_callers(0)
+    nn.set_coalesce(0, 0)
+    assert slow > 0.05 and fast < 0.02, (slow, fast)
+    with pytest.raises(KamiError):
+        nn.set_coalesce_callers(L.KH_MAX_OUTSTANDING + 1)
+
+
 def test_queue_attributes_nan_to_the_submission_that_holds_it():
     F, C, R = 30, 64, 1
     nn = NN(8, 8, F, 4672, filters=C, residuals=R, dtype="bf16")
