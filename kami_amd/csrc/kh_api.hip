@@ -625,8 +625,11 @@ int forward_simple(kh_engine* e, const Weights& W, Slot& s, const float* d_in, i
 }
 
 // The throughput path: one persistent kernel for the whole forward pass (tower_mfma.hip).
+struct LegalDev { const int32_t* offsets; const int32_t* actions; float* priors; float* values; int* flags; };
+
 int forward_tower(kh_engine* e, const Weights& W, Slot& s, const float* d_in, int B,
-                  float* d_policy, float* d_vfull, float* d_logits_out, const kh_board* d_boards = nullptr)
+                  float* d_policy, float* d_vfull, float* d_logits_out, const kh_board* d_boards = nullptr,
+                  const LegalDev* lg = nullptr)
 {
     if (!W.tw_ok) return fail(KH_ERR_INVALID, "bf16/f16 path unavailable for this configuration: %s", W.tw_why.c_str());
     if (!d_boards && (reinterpret_cast<uintptr_t>(d_in) & 15)) return fail(KH_ERR_INVALID, "input planes must be 16-byte aligned");
@@ -642,6 +645,7 @@ int forward_tower(kh_engine* e, const Weights& W, Slot& s, const float* d_in, in
     a.params = W.tw_par.as<float>(); a.npar = W.tw_npar;
     a.fcw4 = W.tw_fc4.as<float>(); a.fcb = W.tw_fc4.as<float>() + (size_t)KH_VALUE_WIDTH * 64;
     a.policy = d_policy; a.vfull = d_vfull; a.logits = d_logits_out; a.flags = flags;
+    if (lg) { a.lg_offsets = lg->offsets; a.lg_actions = lg->actions; a.lg_priors = lg->priors; a.lg_values = lg->values; a.lg_flags = lg->flags; }
     HIPCHK(kh::launch_tower(e->cfg.dtype, W.tw_FP, a, e->num_cus, st));
     return KH_OK;
 }
@@ -1004,14 +1008,19 @@ int co_run_legal_direct(kh_engine* e, CoBatch& b)
     Slot& s = b.slot;
     if ((rc = slot_ensure(e, s, B, true))) return rc;
     hipStream_t st = s.stream;
-    if (fused_ingest(e, *W)) rc = forward_tower(e, *W, s, nullptr, B, s.policy.as<float>(), s.vfull.as<float>(), nullptr, b.boards);
-    else {
+    if (fused_ingest(e, *W)) {
+        // one launch: records in, legal priors + values + NaN flags out, all through the batch's page-locked blocks
+        b.flags_out[0] = b.flags_out[1] = 0;
+        const LegalDev lg{ b.offsets, b.actions, b.priors, b.values, b.flags_out };
+        rc = forward_tower(e, *W, s, nullptr, B, s.policy.as<float>(), s.vfull.as<float>(), nullptr, b.boards, &lg);
+        if (rc) return rc;
+    } else {
         kh::launch_encode_f32(b.boards, B, s.planes.as<float>(), st);
         rc = forward_dispatch(e, *W, s, s.planes.as<float>(), B, s.policy.as<float>(), s.vfull.as<float>(), nullptr);
+        if (rc) return rc;
+        kh::launch_gather_legal(s.policy.as<float>(), b.offsets, b.actions, b.priors, B, st, s.vfull.as<float>(), KH_VALUE_WIDTH, b.values,
+                                s.flags.as<int>(), b.flags_out);
     }
-    if (rc) return rc;
-    kh::launch_gather_legal(s.policy.as<float>(), b.offsets, b.actions, b.priors, B, st, s.vfull.as<float>(), KH_VALUE_WIDTH, b.values,
-                            s.flags.as<int>(), b.flags_out);
     HIPCHK(hipGetLastError());
     for (;;) {
         const hipError_t q = hipStreamQuery(st);

@@ -56,6 +56,15 @@ struct TowerArgs {
     float* vfull;            // [B][256]
     float* logits;           // nullable [B][4672]
     int* flags;              // [0] policy NaN, [1] value NaN
+    // Legal-move mode (nullable as a whole: lg_offsets == nullptr): instead of the 4 672-entry policy row the kernel writes
+    // the priors of each board's legal actions, renormalised over them (MCTS::expand, mcts.h:273-276,296 — what
+    // gather_legal_kernel computes from the row, same arithmetic in the same order), one value per board (column 0 of the
+    // value tensor) and the NaN flags, all of it straight into the caller's (page-locked) blocks: one launch per evaluation.
+    const int32_t* lg_offsets = nullptr;   // [B + 1]
+    const int32_t* lg_actions = nullptr;
+    float* lg_priors = nullptr;
+    float* lg_values = nullptr;            // [B]
+    int* lg_flags = nullptr;               // [2], zeroed by the host before the launch; a flagging lane stores 1
 };
 
 // floats of LDS parameter area: shifts of the 1+2R 3x3 layers, policy shifts/bias, value conv, scratch

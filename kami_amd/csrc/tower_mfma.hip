@@ -379,7 +379,16 @@ __device__ __forceinline__ float wave_sum_f(float v)
 }
 
 
+// a NaN verdict (nn.cpp:176-180): OR-ed into the engine's device flags; in legal-move mode also stored to the caller's block
+template <bool LEGAL>
+__device__ __forceinline__ void raise_flag(const TowerArgs& a, int which)
+{
+    atomicOr(&a.flags[which], 1);
+    if (LEGAL) __builtin_nontemporal_store(1, a.lg_flags + which);
+}
+
 // valuefc + tanh -> [B][256] (nn.cpp:86-88): thread j owns output j, its weight row sits in registers
+template <bool LEGAL>
 __device__ __forceinline__ void value_fc(const TowerArgs& a, const float4 (&fcw)[16], float fcbias, const float* v64,
                                          int b0, int tid, int lane)
 {
@@ -403,9 +412,10 @@ __device__ __forceinline__ void value_fc(const TowerArgs& a, const float4 (&fcw)
             const float r = tanhf(s[bb] + fcbias);
             nan |= (r != r);
             a.vfull[(size_t)(b0 + bb) * KH_VALUE_WIDTH + tid] = r;
+            if (LEGAL && tid == 0) a.lg_values[b0 + bb] = r;               // column 0: the position's value
         }
     }
-    if (__any(nan) && lane == 0) atomicOr(&a.flags[1], 1);
+    if (__any(nan) && lane == 0) raise_flag<LEGAL>(a, 1);
 }
 
 
@@ -448,12 +458,13 @@ __device__ __forceinline__ void ingest_half(const float4_u (&v)[4][2], int hh, c
             *reinterpret_cast<u32x2*>(dst + 64 * q) = o;
         }
     }
-    if (__any(bad) && lane == 0) atomicOr(&a.flags[0], 1);
+    if (__any(bad) && lane == 0) raise_flag<false>(a, 0);
 }
 
 // ---------------------------------------------------------------- the kernel
-// KS_STEM = padded input planes / 16 (2 for F <= 32, 8 for F <= 128).
-template <typename T, int KS_STEM>
+// KS_STEM = padded input planes / 16 (2 for F <= 32, 8 for F <= 128).  LEGAL: legal-move mode (TowerArgs::lg_*), its own
+// instantiation so that the plain kernel's code does not change by a single instruction.
+template <typename T, int KS_STEM, bool LEGAL = false>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void tower_kernel(TowerArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -635,7 +646,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                 *reinterpret_cast<u32x4*>(smem + LDS_ST + bb * SBOARD + (((p >> 3) + 1) * PITCH + (p & 7) + 1) * SSTR + (tid % CH) * 16) = o;
             }
             // a NaN/Inf plane value makes the reference's policy NaN (nn.cpp:176): same verdict here
-            if (__any(bad) && lane == 0) atomicOr(&a.flags[0], 1);
+            if (__any(bad) && lane == 0) raise_flag<LEGAL>(a, 0);
         }
         // vector-memory operations of this wave that are younger than the ring's and may still be in
         // flight past this point: the 8 loads of the second plane half
@@ -731,7 +742,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                 }
             const float part = (s01.x + s01.y) + (s23.x + s23.y);
             const unsigned pu = __float_as_uint(part);
-            if ((pu & 0x7f800000u) == 0x7f800000u) atomicOr(&a.flags[0], 1);
+            if ((pu & 0x7f800000u) == 0x7f800000u) raise_flag<LEGAL>(a, 0);
             const auto sw = __builtin_amdgcn_permlane32_swap(pu, pu, false, false);   // {lanes 0-31 twice, lanes 32-63 twice}
             const float sv = __uint_as_float(sw[0]) + __uint_as_float(sw[1]);
             if (h == 0) v64[wb * 64 + py * 8 + px] = relu_nan(sv + vsh[0]);
@@ -818,7 +829,28 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             lds_barrier();
             const float inv = 1.0f / (red[4 + bb * 2] + red[4 + bb * 2 + 1]);
             bool nan = false;
-            if (live) {
+            if (LEGAL) {
+                // legal-move mode: the board's first wave does what gather_legal_kernel does with the stored row — p[a] =
+                // exp(l[a] - m) * inv recomputed from the logits in LDS (the same operations on the same values: the same
+                // bits), summed and renormalised in that kernel's order
+                nan = inv != inv;                           // a NaN logit makes the sum, hence every entry, NaN
+                if (live && (wave & 1) == 0) {
+                    const float* Lb = reinterpret_cast<const float*>(smem + LDS_L + bb * LBOARD);
+                    const int lo = a.lg_offsets[b0 + bb], hi = a.lg_offsets[b0 + bb + 1];
+                    float sum = 0.0f;
+                    // (__fmul_rn: the row's entries are rounded products; no contraction into the sum)
+                    for (int k = lo + lane; k < hi; k += 64) {
+                        const int ac = a.lg_actions[k];
+                        sum += (ac >= 0 && ac < KH_PSIZE) ? __fmul_rn(__expf(Lb[ac] - m), inv) : 0.0f;
+                    }
+                    sum = wave_sum_f(sum);
+                    const float rn = sum > 0.0f ? 1.0f / sum : 0.0f;
+                    for (int k = lo + lane; k < hi; k += 64) {
+                        const int ac = a.lg_actions[k];
+                        a.lg_priors[k] = (ac >= 0 && ac < KH_PSIZE) ? __fmul_rn(__fmul_rn(__expf(Lb[ac] - m), inv), rn) : 0.0f;
+                    }
+                }
+            } else if (live) {
                 float4* po = reinterpret_cast<float4*>(a.policy + (size_t)(b0 + bb) * KH_PSIZE);
 #pragma unroll
                 for (int k = 0; k < 10; ++k) {
@@ -832,28 +864,28 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                     }
                 }
             }
-            if (__any(nan) && lane == 0) atomicOr(&a.flags[0], 1);
+            if (__any(nan) && lane == 0) raise_flag<LEGAL>(a, 0);
         }
 
         // ---- 4e. value head, second half: valuefc + tanh -> [B][256]            nn.cpp:86-88
-        value_fc(a, fcw, fcbias, v64, b0, tid, lane);
+        value_fc<LEGAL>(a, fcw, fcbias, v64, b0, tid, lane);
         lds_barrier();      // L / v64 are dead; the next group may overwrite them
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // drain the prefetch ring before exit
 }
 
-template <typename T, int KS_STEM> static hipError_t launch(const TowerArgs& a, int grid, hipStream_t s)
+template <typename T, int KS_STEM, bool LEGAL = false> static hipError_t launch(const TowerArgs& a, int grid, hipStream_t s)
 {
     constexpr int FP = KS_STEM * 16;
     const int lds = LDS_ST + st_size(FP) + tower_par_floats(a.R) * 4;
     static std::atomic<bool> attr_done{ false };      // engines are called from many host threads; setting it twice is harmless
     if (!attr_done.load(std::memory_order_acquire)) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&tower_kernel<T, KS_STEM>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&tower_kernel<T, KS_STEM, LEGAL>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) return e;
         attr_done.store(true, std::memory_order_release);
     }
-    hipLaunchKernelGGL((tower_kernel<T, KS_STEM>), dim3(grid), dim3(256), lds, s, a);
+    hipLaunchKernelGGL((tower_kernel<T, KS_STEM, LEGAL>), dim3(grid), dim3(256), lds, s, a);
     return hipGetLastError();
 }
 
@@ -866,6 +898,10 @@ hipError_t launch_tower(int dtype, int FP, const TowerArgs& a, int num_cus, hipS
 {
     const int ngroups = (a.B + TW_NB - 1) / TW_NB;
     const int grid = ngroups < num_cus ? ngroups : num_cus;      // one workgroup per CU (LDS-bound residency)
+    if (a.lg_offsets) {                      // legal-move mode: compact records (F <= 32) only
+        if (FP != 32 || !a.lg_actions || !a.lg_priors || !a.lg_values || !a.lg_flags) return hipErrorInvalidValue;
+        return dtype == KH_BF16 ? launch<__bf16, 2, true>(a, grid, s) : launch<_Float16, 2, true>(a, grid, s);
+    }
     if (dtype == KH_BF16) return FP == 32 ? launch<__bf16, 2>(a, grid, s) : launch<__bf16, 8>(a, grid, s);
     return FP == 32 ? launch<_Float16, 2>(a, grid, s) : launch<_Float16, 8>(a, grid, s);
 }

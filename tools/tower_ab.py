@@ -37,9 +37,9 @@ else:
     os.makedirs("gpurun_out", exist_ok=True)
     for rnd in range(2):
         for tag, lib in (("A", a), ("B", b)):
-            r = subprocess.run([sys.executable, __file__, "--one", lib, f"gpurun_out/ab_{tag}.npz"], capture_output=True, text=True, timeout=280)
+            r = subprocess.run([sys.executable, __file__, "--one", lib, f"/tmp/kami_ab_{tag}.npz"], capture_output=True, text=True, timeout=280)
             print(tag, r.stdout.strip(), r.stderr.strip()[-300:] if r.returncode else "", flush=True)
-    A, B = np.load("gpurun_out/ab_A.npz"), np.load("gpurun_out/ab_B.npz")
+    A, B = np.load("/tmp/kami_ab_A.npz"), np.load("/tmp/kami_ab_B.npz")
     for k in A.files:
         same = np.array_equal(A[k].view(np.uint32), B[k].view(np.uint32))
         print(k, "bit-identical" if same else f"DIFFERENT: max |d| {np.abs(A[k] - B[k]).max():.3e}")
