@@ -864,6 +864,30 @@ int infer_host(kh_engine* e, const float* input, const kh_board* boards, int bat
         if (boards) memcpy(s.hin.at(in_boards), boards, B * sizeof(kh_board));
         memcpy(s.hin.at(in_offs), legal->offsets, (B + 1) * 4);
         memcpy(s.hin.at(in_acts), legal->actions, (size_t)nact * 4);
+        if (fused && e->cfg.value_mode == KH_VALUE_PER_SAMPLE0) {
+            // ONE launch, no copy engine: the kernel reads records / offsets / actions from the page-locked block and writes
+            // the legal priors, the values (column 0) and the NaN flags into the other one itself (tower_kernel's
+            // legal-move mode; what the queue's launches do); completion is polled
+            int* fl = reinterpret_cast<int*>(s.hout.at(out_flags));
+            fl[0] = fl[1] = 0;
+            const LegalDev lg{ reinterpret_cast<const int32_t*>(s.hin.at(in_offs)), reinterpret_cast<const int32_t*>(s.hin.at(in_acts)),
+                               reinterpret_cast<float*>(s.hout.at(out_priors)), reinterpret_cast<float*>(s.hout.at(out_values)), fl };
+            rc = forward_tower(e, *W, s, nullptr, batch, s.policy.as<float>(), s.vfull.as<float>(), nullptr,
+                               reinterpret_cast<const kh_board*>(s.hin.at(in_boards)), &lg);
+            if (rc) return rc;
+            for (int k = 0;; ++k) {
+                const hipError_t q = hipStreamQuery(st);
+                if (q == hipSuccess) break;
+                if (q != hipErrorNotReady) return fail(KH_ERR_HIP, "hipStreamQuery failed: %s", hipGetErrorString(q));
+                if ((k & 15) == 15) sched_yield();
+            }
+            memcpy(legal->priors, s.hout.at(out_priors), (size_t)nact * 4);
+            memcpy(value, s.hout.at(out_values), B * 4);
+            if (fl[0] | fl[1]) s.flags_clean = false;
+            if (fl[0]) return fail(KH_ERR_NAN_POLICY, "inference policy output contains NaN");   // nn.cpp:176-177
+            if (fl[1]) return fail(KH_ERR_NAN_VALUE, "inference value output contains NaN");     // nn.cpp:179-180
+            return KH_OK;
+        }
         HIPCHK(hipMemcpyAsync(s.pack_in.p, s.hin.p, in_total, hipMemcpyHostToDevice, st));
         d_boards = reinterpret_cast<const kh_board*>(s.pack_in.as<char>() + in_boards);
     }

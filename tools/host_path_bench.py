@@ -33,4 +33,10 @@ for F in (119, 30):
         offs = (np.arange(B + 1) * 20).astype(np.int32)
         acts = np.tile(np.array([584, 657, 730, 803, 876] * 4, np.int32), B)
         print(f"F=30 B=512: kh_encode_infer {rate(lambda: nn.encode_infer(boards), B):,.0f} evals/s")
-        print(f"F=30 B=512: kh_encode_infer_legal {rate(lambda: nn.infer_legal(boards, offs, acts), B):,.0f} evals/s")
+        print(f"F=30 B=512: kh_encode_infer_legal {rate(lambda: nn.infer_legal(boards, offs, acts), B):,.0f} evals/s (reference value copy-out: pinned block + copy engine)")
+        nn2 = NN(8, 8, F, 4672, filters=64, residuals=6, dtype="bf16", value_mode=L.KH_VALUE_PER_SAMPLE0)
+        nn2.load_weights(W.random_weights(F, 64, 6, seed=1), 1)
+        print(f"F=30 B=512: kh_encode_infer_legal {rate(lambda: nn2.infer_legal(boards, offs, acts), B):,.0f} evals/s (one value per position: ONE launch, no copy engine)")
+        for B2 in (16, 64):
+            b2, o2, a2 = boards[:B2], offs[:B2 + 1], acts[:offs[B2]]
+            print(f"F=30 B={B2}: kh_encode_infer_legal {rate(lambda: nn2.infer_legal(b2, o2, a2), B2, 200):,.0f} evals/s (one launch)")
