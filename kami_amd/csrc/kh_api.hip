@@ -987,7 +987,8 @@ struct CoTicket {
 struct CoBatch {
     int state = 0;                              // 0 free, 1 open, 2 sealed (a lane owns it)
     int kind = 0;                               // 0: records + legal actions -> priors; 1: planes -> full policy rows
-    int rows = 0, nact = 0, copying = 0;
+    int rows = 0, nact = 0;
+    std::atomic<int> copying{ 0 };              // submitters that have reserved rows and are still copying them in
     bool full = false;
     std::chrono::steady_clock::time_point first, last;     // first / latest submission into this batch
     std::vector<CoTicket*> tickets;
@@ -1131,14 +1132,21 @@ void co_lane(Coalescer* c)
         if (!take) {
             if (c->stop) return;
             if (deadline == std::chrono::steady_clock::time_point::max()) c->cv_lane.wait(lk);
-            else c->cv_lane.wait_until(lk, deadline);
+            else {
+                // a batch is filling and will go within wait_us at the latest: poll for it instead of sleeping — the
+                // wake-up of a sleeping lane (5-15 us) would be paid by every caller of the launch
+                lk.unlock();
+                for (int k = 0; k < 32; ++k) __builtin_ia32_pause();
+                sched_yield();
+                lk.lock();
+            }
             continue;
         }
         take->state = 2;
         ++c->lanes_busy;
         const auto t_seal = std::chrono::steady_clock::now();
-        while (take->copying > 0) c->cv_lane.wait(lk);          // submitters still copying their rows in
         lk.unlock();
+        while (take->copying.load(std::memory_order_acquire) > 0) __builtin_ia32_pause();   // submitters still copying their rows in: a microsecond
         const auto t_run = std::chrono::steady_clock::now();
         co_run_batch(e, *take);
         const auto t_ran = std::chrono::steady_clock::now();
@@ -1263,7 +1271,7 @@ int co_submit(kh_engine* e, int kind, const kh_board* boards, const float* plane
     t->priors = priors; t->value = value; t->policy = policy;
     b->rows += batch; b->nact += nact;
     b->tickets.push_back(t);
-    ++b->copying;
+    b->copying.fetch_add(1, std::memory_order_relaxed);
     b->last = std::chrono::steady_clock::now();           // (under the lock: the lanes read it there)
     lk.unlock();
     // this caller's rows into the merge buffers (every caller copies its own, in parallel)
@@ -1274,11 +1282,11 @@ int co_submit(kh_engine* e, int kind, const kh_board* boards, const float* plane
     } else {
         memcpy(b->planes.data() + (size_t)t->row0 * 64 * F, planes, (size_t)batch * 64 * F * 4);
     }
-    lk.lock();
-    --b->copying;
-    lk.unlock();
+    const uint32_t serial = t->serial;
+    b->copying.fetch_sub(1, std::memory_order_release);   // (no lock: the lane that has sealed this batch spins on it; after
+                                                          //  this the launch may complete and the ticket be waited for)
     c->cv_lane.notify_all();
-    *ticket = (int64_t)tid | ((int64_t)t->serial << 32);
+    *ticket = (int64_t)tid | ((int64_t)serial << 32);
     return KH_OK;
 }
 
