@@ -1047,11 +1047,11 @@ int co_run_legal_direct(kh_engine* e, CoBatch& b)
                                 s.flags.as<int>(), b.flags_out);
     }
     HIPCHK(hipGetLastError());
-    for (;;) {
+    for (int k = 0;; ++k) {
         const hipError_t q = hipStreamQuery(st);
         if (q == hipSuccess) break;
         if (q != hipErrorNotReady) return fail(KH_ERR_HIP, "hipStreamQuery failed: %s", hipGetErrorString(q));
-        sched_yield();                          // the callers' threads may need this core: poll, but never hog
+        if ((k & 7) == 7) sched_yield();        // the callers' threads may need this core: poll, but never hog
     }
     if (b.flags_out[0] | b.flags_out[1]) s.flags_clean = false;
     if (b.flags_out[0]) return fail(KH_ERR_NAN_POLICY, "inference policy output contains NaN");   // nn.cpp:176-177
