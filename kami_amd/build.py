@@ -21,10 +21,10 @@ CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(CSRC, "build")
 LIB = os.path.join(HERE, "libkamihip.so")
 ARCH = "gfx950"
-SOURCES = ["kh_api.hip", "encode.hip", "forward_simple.hip", "tower_mfma.hip", "layers_mfma.hip", "train.hip"]
+SOURCES = ["kh_api.hip", "encode.hip", "forward_simple.hip", "tower_mfma.hip", "tower8_mfma.hip", "layers_mfma.hip", "train.hip"]
 # MFMA results in arch VGPRs: the epilogues read them with VALU ops and would otherwise pay a
 # v_accvgpr_read per value (the kernel runs one wave per SIMD, registers are not scarce).
-EXTRA_FLAGS = {"tower_mfma.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"]}
+EXTRA_FLAGS = {"tower_mfma.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"], "tower8_mfma.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"]}
 # (tools/wide_stamps.py and tools/t128_stamps.py use a separate diagnostic object of layers_mfma.hip built with
 #  -DKAMI_WIDE_DIAG — in-kernel s_memtime stamps — linked into csrc/build/libkamihip_diag.so by tools/build_diag.sh;
 #  the shipped library never contains it, and tower_mfma.hip has no diagnostic variants any more.)

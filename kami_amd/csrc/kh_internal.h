@@ -72,6 +72,9 @@ __host__ __device__ constexpr int tower_par_copy_floats(int R) { return (1 + 2 *
 __host__ __device__ constexpr int tower_par_floats(int R) { return tower_par_copy_floats(R) + TW_NB * 64 + 16; }
 int tower_lds_bytes(int FP, int R);
 hipError_t launch_tower(int dtype, int FP, const TowerArgs& a, int num_cus, hipStream_t s);
+// tower8_mfma.hip: the same forward with specialised waves (4 compute + 4 helper waves per workgroup); launch_tower
+// dispatches to it (KAMI_TOWER_V=4|8 overrides the build's default for A/B runs)
+hipError_t launch_tower8(int dtype, int FP, const TowerArgs& a, int num_cus, hipStream_t s);
 
 // ---- layers_mfma.hip ----------------------------------------------------------------------
 // bf16 / f16 path for wide nets (65..256 filters): one MFMA kernel launch per layer.

@@ -1,0 +1,619 @@
+// tower8_mfma.hip — the whole network forward (kami/nn/nn.cpp:59-91) as one persistent gfx950 kernel with
+// SPECIALISED waves: 512 threads per workgroup = 4 compute waves (one per SIMD: the MFMAs, the epilogues, the
+// softmax) + 4 helper waves (one per SIMD beside them: the weight stream's LDS-DMA, the plane ingest, the value FC).
+//
+// Why: tower_mfma.hip's four waves do everything themselves, and with ONE wave per SIMD every instruction that is
+// not an MFMA and does not fit a 24-cycle MFMA gap stops the matrix pipe.  Measured on that kernel (same-process A/B,
+// profiles/r03_tower_ablations_v1.txt; phase stamps, profiles/r03_tower_stamps_v1.txt): the two LDS-DMA pieces per
+// step cost 3.8 us of 36, the plane ingest keeps the matrix pipe idle for the first 9 500 cycles of 72 400, the heads'
+// VALU work and the value FC for most of the last 11 700.  A helper wave's VMEM / VALU / LDS instructions issue
+// beside the compute wave's MFMAs (different instruction types of different waves issue in the same cycle), so here
+// the compute waves' stream is: barrier, operand reads, MFMAs, epilogue.
+//
+// Same data layout, same weight stream, same arithmetic in the same order as tower_mfma.hip (geometry and helpers:
+// tower_common.h): the convolutions' results are bit-identical to that kernel's (tools/tower_ablate.py).
+//
+// Barriers: s_barrier counts all 8 waves, so both roles execute exactly the same number of them per board group —
+// every barrier below is tagged [B..] in both paths.
+#include "tower_common.h"
+
+#include <atomic>
+#include <cstdlib>
+
+#ifndef KAMI_TOWER_STAMP
+#define KAMI_TOWER_STAMP 0
+#endif
+#if KAMI_TOWER_STAMP
+#define T8_STAMP(k) do { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); if (lane == 0) stamps[wave * 32 + (k)] = t_; } while (0)
+#else
+#define T8_STAMP(k) do { } while (0)
+#endif
+
+namespace kh {
+
+// ---------------------------------------------------------------- ring protocol, two roles
+// Chunk c lives in slot c mod RING_D.  Step c of a compute wave multiplies chunk c (in registers since step c - 1)
+// and reads chunk c + 1 into its other register set.  Before barrier c a helper wave has waited for its two pieces of
+// chunk c + 1; after it, it refills slot (c - 1) mod RING_D — whose chunk every compute wave finished reading two
+// steps ago — with chunk c + RING_D - 1.  A chunk is requested RING_D - 2 steps before it is read.
+struct CPipe { unsigned ring; int cslot; };
+
+__device__ __forceinline__ unsigned cpipe_step(CPipe& p)
+{
+    asm volatile("s_barrier" ::: "memory");
+    // nothing moves across the step boundary (see tower_mfma.hip: the register double buffer would collapse)
+    __builtin_amdgcn_sched_barrier(0);
+    p.cslot = (p.cslot + 1 == RING_D) ? 0 : p.cslot + 1;
+    return p.ring + p.cslot * CHUNK;
+}
+
+// VMX: vector-memory operations of this helper wave that are YOUNGER than the ring's and may stay in flight
+template <int VMX>
+__device__ __forceinline__ void hpipe_step(Pipe& p, int hw, int lane)
+{
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * (RING_D - 3) + VMX) : "memory");
+    asm volatile("s_barrier" ::: "memory");
+    pipe_issue(p, hw, lane);
+}
+
+// ---------------------------------------------------------------- implicit-GEMM layer, compute-wave side
+// tower_mfma.hip's gemm_layer without the stream's issue side (template parameters as there).
+template <typename T, int TAPS, int KS, int MS, int PAR, int NREG = 0, bool CF = false, int TAILV = 0>
+__device__ __forceinline__ void gemm8_layer(CPipe& p, const char* smem, int lane, unsigned b_base, int stride,
+                                            f32x16 (&acc)[MS], typename Elem<T>::vec8 (&A)[2][8],
+                                            const typename Elem<T>::vec8* breg = nullptr)
+{
+    using V = typename Elem<T>::vec8;
+    using S = LayerShape<TAPS, KS, MS>;
+    constexpr int KPC = S::KPC;
+    V B[2][KPC];
+#pragma unroll
+    for (int k = 0; k < KPC; ++k) {
+        if (k < NREG) B[PAR][k] = breg[k];
+        else B[PAR][k] = *reinterpret_cast<const V*>(smem + b_base + b_offset<TAPS, KS, CF>(k, stride));
+    }
+#pragma unroll
+    for (int n = 0; n < S::NCH; ++n) {
+        const int cur = (PAR + n) & 1, nxt = cur ^ 1;
+        const unsigned a_off = cpipe_step(p) + lane * 16;
+#pragma unroll
+        for (int f = 0; f < 8; ++f) A[nxt][f] = *reinterpret_cast<const V*>(smem + a_off + f * 1024);
+        if (n + 1 < S::NCH) {
+#pragma unroll
+            for (int k = 0; k < KPC; ++k) {
+                if ((n + 1) * KPC + k < NREG) B[nxt][k] = breg[(n + 1) * KPC + k];
+                else B[nxt][k] = *reinterpret_cast<const V*>(smem + b_base + b_offset<TAPS, KS, CF>((n + 1) * KPC + k, stride));
+            }
+        }
+        if (TAILV > 0 && n == S::NCH - 1) {
+            // last chunk, tile-major: tile 0 is final four MFMAs early, its epilogue runs under tile 1's MFMAs
+#pragma unroll
+            for (int ms = 0; ms < MS; ++ms)
+#pragma unroll
+                for (int k = 0; k < KPC; ++k) acc[ms] = Elem<T>::mfma(A[cur][k * MS + ms], B[cur][k], acc[ms]);
+#pragma unroll
+            for (int i = 0; i < KPC; ++i) {
+                __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);   // DS read (next layer's first weights)
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // MFMA tile 0
+            }
+#pragma unroll
+            for (int i = 0; i < (MS - 1) * KPC; ++i) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // MFMA tile 1..
+                if (i > 0) __builtin_amdgcn_sched_group_barrier(0x002, TAILV, 0);   // VALU: tile 0's epilogue
+            }
+            continue;
+        }
+#pragma unroll
+        for (int k = 0; k < KPC; ++k)
+#pragma unroll
+            for (int ms = 0; ms < MS; ++ms) acc[ms] = Elem<T>::mfma(A[cur][k * MS + ms], B[cur][k], acc[ms]);
+        // the next chunk's operand reads go out two per MFMA from the top of the step
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);   // DS read
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // MFMA
+        }
+    }
+}
+
+// A chunk of zeros in the stream that only flips the register-set parity back to 0.
+template <typename T, int PAR>
+__device__ __forceinline__ void gemm8_dummy(CPipe& p, const char* smem, int lane, typename Elem<T>::vec8 (&A)[2][8])
+{
+    using V = typename Elem<T>::vec8;
+    const unsigned a_off = cpipe_step(p) + lane * 16;
+#pragma unroll
+    for (int f = 0; f < 8; ++f) A[PAR ^ 1][f] = *reinterpret_cast<const V*>(smem + a_off + f * 1024);
+}
+
+// zero the halo pixels of the two images of `stride` bytes per pixel at `base` (256 threads)
+template <int STRIDE>
+__device__ __forceinline__ void zero_halo(char* base, int board_bytes, int t)
+{
+    const u32x4 z = { 0, 0, 0, 0 };
+    for (int i = t; i < TW_NB * NPIX; i += 256) {
+        const int pp = i % NPIX, yy = pp / PITCH, xx = pp % PITCH;
+        if (yy >= 1 && yy <= 8 && xx >= 1 && xx <= 8) continue;
+        char* d = base + (i / NPIX) * board_bytes + pp * STRIDE;
+#pragma unroll
+        for (int k = 0; k < STRIDE / 16; ++k) *reinterpret_cast<u32x4*>(d + k * 16) = z;
+    }
+}
+
+// ---------------------------------------------------------------- the kernel
+// KS_STEM = padded input planes / 16 (2 for F <= 32, 8 for F <= 128); LEGAL: legal-move mode (TowerArgs::lg_*).
+template <typename T, int KS_STEM, bool LEGAL = false>
+__global__ __launch_bounds__(512) void tower8_kernel(TowerArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int FP = KS_STEM * 16;
+    constexpr int SSTR = FP * 2 + 16;
+    constexpr int SBOARD = NPIX * SSTR;
+    constexpr int ST_SIZE = st_size(FP);
+    constexpr int LDS_PAR = LDS_ST + ST_SIZE;
+    constexpr int LDS_L = LDS_X;
+    using V = typename Elem<T>::vec8;
+    // steps (= chunks = barriers) per board group, phase by phase: both roles walk exactly these
+    constexpr int NSTEM = KS_STEM == 8 ? 2 * LayerShape<9, 4, 2>::NCH : LayerShape<9, KS_STEM, 2>::NCH;
+    constexpr int P1 = NSTEM & 1;                            // register-set parity after the stem
+    constexpr int NLAYER = LayerShape<9, TW_CP / 16, 2>::NCH;                                   // 9 per 3x3 layer
+    constexpr int NPOL = LayerShape<1, TW_CP / 16, 4>::NCH + LayerShape<1, KH_POLICY_MID / 16, 4>::NCH + (P1 ? 1 : 0);
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int ct = tid & 255;              // thread index within the role
+    const int cw = wave & 3;               // wave index within the role
+    const int R = a.R, F = a.F;
+
+    float* par = reinterpret_cast<float*>(smem + LDS_PAR);
+    const float* shift3 = par;                              // [(1 + 2R)][64]
+    const float* pshift1 = par + (1 + 2 * R) * TW_CP;       // [128]
+    const float* pbias2 = pshift1 + KH_POLICY_MID;          // [128] (73 real)
+    const float* vw = pbias2 + 128;                         // [64] valueconv weight * bn scale
+    const float* vsh = vw + TW_CP;                          // [4]  folded valueconv/bn shift
+    float* v64 = const_cast<float*>(vsh) + 4;               // [TW_NB][64] scratch
+    float* red = v64 + TW_NB * 64;                          // [16] reduction scratch
+#if KAMI_TOWER_STAMP
+    unsigned long long* stamps = reinterpret_cast<unsigned long long*>(smem + ((LDS_PAR + tower_par_floats(6) * 4 + 15) & ~15));
+    if (lane == 0) stamps[wave * 32 + 30] = __builtin_amdgcn_s_memrealtime();
+    T8_STAMP(0);
+#endif
+    const int ngroups = (a.B + TW_NB - 1) / TW_NB;
+
+    if (wave >= 4) {
+        // =====================================================================================  helper waves
+        Pipe pipe;
+        pipe.stream = a.wstream; pipe.nch = a.nchunks; pipe.next = 0; pipe.islot = 0; pipe.cslot = 0; pipe.ring = LDS_RING;
+        bool first = true;
+        float4 fcw[16];                                     // valuefc row of output j = ct: fetched once, during the first tower
+        float fcbias = 0.0f;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) fcw[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+
+        for (int grp = blockIdx.x; grp < ngroups; grp += gridDim.x) {
+            const int b0 = grp * TW_NB;
+            if (KS_STEM == 8) {
+                // ---- planes, 33..128 of them: the stem runs as two 64-channel passes; both halves are requested up
+                //      front (the first group's ring prologue between them), the first is converted before [B0], the
+                //      second lands under the first pass and is converted between steps 3 and 4.  Item j of a thread
+                //      = (board, pixel) ct/8 + 32 j, channels 64 hh + 4 (ct%8) .. +3 and +32; loads are clamped into
+                //      the row / batch and masked afterwards so that every wave issues exactly 8 per half.
+                float4_u pl[2][4][2];
+#pragma unroll
+                for (int hh = 0; hh < 2; ++hh) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const int bp = (ct >> 3) + 32 * j;
+                        const int brd = min(b0 + (bp >> 6), a.B - 1);
+                        const float* row = a.in + ((size_t)brd * 64 + (bp & 63)) * F;
+                        const int c = hh * 64 + 4 * (ct & 7);
+                        pl[hh][j][0] = __builtin_nontemporal_load(reinterpret_cast<const float4_u*>(row + min(c, F - 4)));
+                        pl[hh][j][1] = __builtin_nontemporal_load(reinterpret_cast<const float4_u*>(row + min(c + 32, F - 4)));
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (hh == 0 && first) {
+#pragma unroll
+                        for (int i = 0; i < RING_D - 1; ++i) pipe_issue(pipe, cw, lane);
+                    }
+                }
+                // the first half and everything older (ring chunks 0..4 of the first group) have landed
+                asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+                ingest_half<T>(pl[0], 0, smem + LDS_ST, SSTR, SBOARD, b0, ct, lane, a);
+                lds_barrier();                                                              // [B0]
+                first = false;
+                T8_STAMP(2);
+                // pass 1's first RING_D - 2 steps need chunks requested before the second half's loads
+#pragma unroll
+                for (int i = 0; i < RING_D - 2; ++i) hpipe_step<8>(pipe, cw, lane);
+                ingest_half<T>(pl[1], 1, smem + LDS_ST, SSTR, SBOARD, b0, ct, lane, a);
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                for (int i = RING_D - 2; i < NSTEM; ++i) hpipe_step<0>(pipe, cw, lane);
+            } else {
+                if (first) {
+#pragma unroll
+                    for (int i = 0; i < RING_D - 1; ++i) pipe_issue(pipe, cw, lane);
+                }
+                if (a.boards) {
+                    // ---- compact ingest: Env::observe (env.h:202-262) straight into S, one thread per (board, square)
+                    if (ct < TW_NB * 64) {
+                        const int bb = ct >> 6, p = ct & 63;
+                        float v[32];
+#pragma unroll
+                        for (int k = 0; k < 32; ++k) v[k] = 0.0f;
+                        if (b0 + bb < a.B) {
+                            float w[KH_NFEATURES];
+                            encode_square(a.boards + (b0 + bb), p, w);
+#pragma unroll
+                            for (int k = 0; k < KH_NFEATURES; ++k) v[k] = w[k];
+                        }
+                        char* dst = smem + LDS_ST + bb * SBOARD + (((p >> 3) + 1) * PITCH + (p & 7) + 1) * SSTR;
+#pragma unroll
+                        for (int c = 0; c < 4; ++c) {
+                            u32x4 o;
+                            o.x = pack2<T>(v[8 * c + 0], v[8 * c + 1]); o.y = pack2<T>(v[8 * c + 2], v[8 * c + 3]);
+                            o.z = pack2<T>(v[8 * c + 4], v[8 * c + 5]); o.w = pack2<T>(v[8 * c + 6], v[8 * c + 7]);
+                            *reinterpret_cast<u32x4*>(dst + c * 16) = o;
+                        }
+                    }
+                } else {
+                    // ---- planes fp32 [b][64][F], F <= 32 -> T in S (interior pixels, all FP channels)
+                    constexpr int CH = FP / 8;                       // 8-channel (16-byte) chunks per pixel of S
+                    constexpr int NIT = TW_NB * 64 * CH / 256;       // (board, pixel, chunk) items per thread
+                    float vin[NIT][8];
+                    const int c0 = (ct % CH) * 8;
+#pragma unroll
+                    for (int j = 0; j < NIT; ++j) {
+                        const int i = ct + 256 * j;
+                        const int bb = i / (64 * CH), p = (i / CH) & 63;
+                        const float* src = a.in + ((size_t)(b0 + bb) * 64 + p) * F + c0;
+                        const bool live = (b0 + bb) < a.B;
+                        if (live && c0 + 8 <= F) {
+                            const float4_u lo = *reinterpret_cast<const float4_u*>(src);
+                            const float4_u hi = *reinterpret_cast<const float4_u*>(src + 4);
+                            vin[j][0] = lo.x; vin[j][1] = lo.y; vin[j][2] = lo.z; vin[j][3] = lo.w;
+                            vin[j][4] = hi.x; vin[j][5] = hi.y; vin[j][6] = hi.z; vin[j][7] = hi.w;
+                        } else {
+#pragma unroll
+                            for (int k = 0; k < 8; ++k) vin[j][k] = (live && c0 + k < F) ? src[k] : 0.0f;
+                        }
+                    }
+                    bool bad = false;
+#pragma unroll
+                    for (int j = 0; j < NIT; ++j) {
+                        const int i = ct + 256 * j;
+                        const int bb = i / (64 * CH), p = (i / CH) & 63;
+                        u32x4 o;
+                        unsigned w[4];
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) {
+                            const float lo = vin[j][2 * k], hi = vin[j][2 * k + 1];
+                            bad = bad || ((__float_as_uint(lo) & 0x7f800000u) == 0x7f800000u) || ((__float_as_uint(hi) & 0x7f800000u) == 0x7f800000u);
+                            w[k] = pack2<T>(lo, hi);
+                        }
+                        o.x = w[0]; o.y = w[1]; o.z = w[2]; o.w = w[3];
+                        *reinterpret_cast<u32x4*>(smem + LDS_ST + bb * SBOARD + (((p >> 3) + 1) * PITCH + (p & 7) + 1) * SSTR + (ct % CH) * 16) = o;
+                    }
+                    // a NaN/Inf plane value makes the reference's policy NaN (nn.cpp:176): same verdict here
+                    if (__any(bad) && lane == 0) raise_flag<LEGAL>(a, 0);
+                }
+                // everything requested so far has landed: the planes and, in the first group, ring chunks 0..4
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                lds_barrier();                                                              // [B0]
+                first = false;
+                T8_STAMP(2);
+                for (int i = 0; i < NSTEM; ++i) hpipe_step<0>(pipe, cw, lane);
+            }
+            asm volatile("s_barrier" ::: "memory");                                         // [B1]
+            T8_STAMP(5);
+            // tower + policy steps.  In the first group the valuefc row is requested here: 17 loads younger than
+            // the ring's, which the next RING_D - 2 steps' waits leave in flight.
+            int relax = 0;
+            if (grp == (int)blockIdx.x) {
+#pragma unroll
+                for (int k = 0; k < 16; ++k)
+                    fcw[k] = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(a.fcw4) + (size_t)k * KH_VALUE_WIDTH * 16 + (unsigned)ct * 16u);
+                fcbias = a.fcb[ct];
+                __builtin_amdgcn_sched_barrier(0);
+                relax = RING_D - 2;
+            }
+            const int nsteps = 2 * R * NLAYER + NPOL;
+            for (int i = 0; i < nsteps; ++i) {
+                if (relax > 0) { hpipe_step<17>(pipe, cw, lane); --relax; }
+                else hpipe_step<0>(pipe, cw, lane);
+            }
+            T8_STAMP(19);
+            asm volatile("s_barrier" ::: "memory");                                         // [BL] logits in LDS; v64 since 4a
+            // ---- value head, second half: valuefc + tanh -> [B][256] (nn.cpp:86-88), under the compute waves' softmax
+            {
+                float s[TW_NB];
+#pragma unroll
+                for (int bb = 0; bb < TW_NB; ++bb) s[bb] = 0.0f;
+#pragma unroll
+                for (int k = 0; k < 16; ++k) {
+                    const float4 w = fcw[k];
+#pragma unroll
+                    for (int bb = 0; bb < TW_NB; ++bb) {
+                        const float4 x = *reinterpret_cast<const float4*>(v64 + bb * 64 + k * 4);
+                        s[bb] = fmaf(x.x, w.x, s[bb]); s[bb] = fmaf(x.y, w.y, s[bb]);
+                        s[bb] = fmaf(x.z, w.z, s[bb]); s[bb] = fmaf(x.w, w.w, s[bb]);
+                    }
+                }
+                bool nan = false;
+#pragma unroll
+                for (int bb = 0; bb < TW_NB; ++bb) {
+                    if (b0 + bb < a.B) {
+                        const float r = tanhf(s[bb] + fcbias);
+                        nan |= (r != r);
+                        a.vfull[(size_t)(b0 + bb) * KH_VALUE_WIDTH + ct] = r;
+                        if (LEGAL && ct == 0) a.lg_values[b0 + bb] = r;               // column 0: the position's value
+                    }
+                }
+                if (__any(nan) && lane == 0) raise_flag<LEGAL>(a, 1);
+            }
+            T8_STAMP(21);
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");                 // [BS1]
+            asm volatile("s_barrier" ::: "memory");                                         // [BS2]
+            asm volatile("s_barrier" ::: "memory");                                         // [BE]
+            T8_STAMP(22);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // drain the prefetch ring before exit
+    } else {
+        // =====================================================================================  compute waves
+        const int h = lane >> 5;
+        // this wave's 32-pixel column tile: board cw>>1, rows 4*(cw&1)..+3
+        const int wb = cw >> 1;
+        const int lp = PIXMAP[lane & 31];
+        const int py = 4 * (cw & 1) + (lp >> 3), px = lp & 7;
+        const unsigned xin = LDS_X + wb * XBOARD + (py * PITCH + px) * XSTR + h * 16;       // tap (0,0) = pixel (y-1,x-1)
+        const unsigned tin = LDS_ST + wb * XBOARD + (py * PITCH + px) * XSTR + h * 16;
+        const unsigned sin = LDS_ST + wb * SBOARD + (py * PITCH + px) * SSTR + h * 16;
+        const unsigned xout = LDS_X + wb * XBOARD + ((py + 1) * PITCH + px + 1) * XSTR;     // own pixel
+        const unsigned tout = LDS_ST + wb * XBOARD + ((py + 1) * PITCH + px + 1) * XSTR;
+
+        CPipe pipe;
+        pipe.ring = LDS_RING; pipe.cslot = 0;
+        // parameter block -> LDS
+        for (int i = ct; i < a.npar; i += 256) par[i] = a.params[i];
+        T8_STAMP(1);
+
+        V A[2][8];                             // two register sets of weight fragments (current / next chunk)
+        bool first = true;
+
+        for (int grp = blockIdx.x; grp < ngroups; grp += gridDim.x) {
+            const int b0 = grp * TW_NB;
+            // zero the halo pixels of X and S (the previous group's logits lived there); the helpers fill S's interior
+            zero_halo<XSTR>(smem + LDS_X, XBOARD, ct);
+            zero_halo<SSTR>(smem + LDS_ST, SBOARD, ct);
+            T8_STAMP(2);
+            lds_barrier();                                                                  // [B0]
+            if (first) {
+                first = false;
+#pragma unroll
+                for (int f = 0; f < 8; ++f) A[0][f] = *reinterpret_cast<const V*>(smem + LDS_RING + lane * 16 + f * 1024);
+            }
+
+            // This wave's tile of the residual stream (its own 32 pixels x 64 channels), packed: the skip operand,
+            // the centre-tap operand of the next conv and the input of both heads; X carries it for the neighbours' taps.
+            Packed<2> xk;
+            f32x16 xf[2];          // the same tile in fp32: the skip operand and the value head's input
+            T8_STAMP(3);
+            // ---- stem: conv1 + batchnorm1 + relu, S -> X                           nn.cpp:62-65
+            {
+                f32x16 acc[2];
+                acc_init<2>(acc, shift3, h);
+                if (KS_STEM == 8) {
+                    gemm8_layer<T, 9, 4, 2, 0>(pipe, smem, lane, sin, SSTR, acc, A);            // planes 0..63
+                    gemm8_layer<T, 9, 4, 2, 1>(pipe, smem, lane, sin + 128, SSTR, acc, A);      // planes 64..127
+                } else {
+                    gemm8_layer<T, 9, KS_STEM, 2, 0>(pipe, smem, lane, sin, SSTR, acc, A);
+                }
+                T8_STAMP(4);
+                epilogue_residual<T, false>(acc, xf, xk);
+                store_packed<2>(xk, smem, xout, h);
+                lds_barrier();                                                              // [B1]
+                // T shares LDS with S: clear T's halo before the tower reads through it
+                zero_halo<XSTR>(smem + LDS_ST, XBOARD, ct);
+            }
+            T8_STAMP(5);
+
+            // ---- residual tower: x = x + relu(bn2(conv2(relu(bn1(conv1 x)))))   nn.cpp:26-34
+            f32x16 accn[2];         // next layer's accumulator start (its folded shifts), fetched a layer ahead
+            acc_init<2>(accn, shift3 + TW_CP, h);
+            for (int r = 0; r < R; ++r) {
+                f32x16 acc[2];
+                V bf[4];
+                packed_fragments<T, 2>(xk, bf);
+                acc[0] = accn[0]; acc[1] = accn[1];
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");          // own image writes done before the step barrier
+                acc_init<2>(accn, shift3 + (2 + 2 * r) * TW_CP, h);
+                gemm8_layer<T, 9, TW_CP / 16, 2, P1, 4, true, 6>(pipe, smem, lane, xin, XSTR, acc, A, bf);
+                T8_STAMP(6 + 2 * r);
+                Packed<2> tk;
+                epilogue_pack<T, 2>(acc, tk);
+                store_packed<2>(tk, smem, tout, h);
+                packed_fragments<T, 2>(tk, bf);
+                acc[0] = accn[0]; acc[1] = accn[1];
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                acc_init<2>(accn, shift3 + (3 + 2 * r) * TW_CP, h);         // (past the last block: the policy shifts, unused)
+                gemm8_layer<T, 9, TW_CP / 16, 2, P1 ^ 1, 4, true, 11>(pipe, smem, lane, tin, XSTR, acc, A, bf);
+                T8_STAMP(7 + 2 * r);
+                epilogue_residual<T, true>(acc, xf, xk);
+                store_packed<2>(xk, smem, xout, h);
+            }
+
+            // ---- value head, first half: valueconv + vbatchnorm + relu (nn.cpp:83-85) on the fp32 tile (see
+            //      tower_mfma.hip 4a: four partial sums, halves joined by one v_permlane32_swap; a NaN or Inf anywhere
+            //      in the residual stream makes the partial sum non-finite: the poisoned-stream detector)
+            {
+                f32x2 s01 = { 0.0f, 0.0f }, s23 = { 0.0f, 0.0f };
+#pragma unroll
+                for (int ms = 0; ms < 2; ++ms)
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        using f32x4 = float __attribute__((ext_vector_type(4)));
+                        const f32x4 w = *reinterpret_cast<const f32x4*>(vw + ms * 32 + 8 * g + 4 * h);
+                        const f32x2 x01 = { xf[ms][4 * g + 0], xf[ms][4 * g + 1] }, x23 = { xf[ms][4 * g + 2], xf[ms][4 * g + 3] };
+                        s01 = x01 * w.xy + s01;
+                        s23 = x23 * w.zw + s23;
+                    }
+                const float part = (s01.x + s01.y) + (s23.x + s23.y);
+                const unsigned pu = __float_as_uint(part);
+                if ((pu & 0x7f800000u) == 0x7f800000u) raise_flag<LEGAL>(a, 0);
+                const auto sw = __builtin_amdgcn_permlane32_swap(pu, pu, false, false);   // {lanes 0-31 twice, lanes 32-63 twice}
+                const float sv = __uint_as_float(sw[0]) + __uint_as_float(sw[1]);
+                if (h == 0) v64[wb * 64 + py * 8 + px] = relu_nan(sv + vsh[0]);
+            }
+            T8_STAMP(18);
+
+            // ---- policy head: policyconv + pbatchnorm + relu (nn.cpp:72-74), 1x1: the operand is the wave's own tile
+            Packed<4> pk;
+            {
+                f32x16 acc[4];
+                V bf[4];
+                packed_fragments<T, 2>(xk, bf);
+                acc_init<4>(acc, pshift1, h);
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");          // v64 written before the next barrier
+                gemm8_layer<T, 1, TW_CP / 16, 4, P1, 4>(pipe, smem, lane, 0, 0, acc, A, bf);
+                T8_STAMP(19);
+                epilogue_pack<T, 4>(acc, pk);
+            }
+            // ---- policyconv2 (+bias): -> logits L[board][pixel*73 + plane]      nn.cpp:75-79
+            {
+                f32x16 acc[4];                  // 73 planes padded to 128 rows: whole 2-k-step chunks
+                V bf[8];
+                packed_fragments<T, 4>(pk, bf);
+                acc_init<4>(acc, pbias2, h);
+                gemm8_layer<T, 1, KH_POLICY_MID / 16, 4, P1, 8>(pipe, smem, lane, 0, 0, acc, A, bf);
+                if (P1) gemm8_dummy<T, 1>(pipe, smem, lane, A);      // stream parity back to 0 for the next group
+                float* lrow = reinterpret_cast<float*>(smem + LDS_L + wb * LBOARD) + (py * 8 + px) * KH_POLICY_PLANES;
+#pragma unroll
+                for (int ms = 0; ms < 3; ++ms)      // planes >= 96 are padding
+#pragma unroll
+                    for (int g = 0; g < 4; ++g)
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) {
+                            const int plane = ms * 32 + 8 * g + 4 * h + i;
+                            if (plane < KH_POLICY_PLANES) lrow[plane] = acc[ms][4 * g + i];
+                        }
+                lds_barrier();                                                              // [BL]
+            }
+            T8_STAMP(20);
+
+            // ---- softmax over all 4672 logits of a board (nn.cpp:80): 128 threads per board, one LDS pass, each
+            //      thread keeps its <= 10 float4 in registers
+            {
+                const int bb = ct >> 7, tt = ct & 127;
+                const bool live = (b0 + bb) < a.B;
+                const float4* L4 = reinterpret_cast<const float4*>(smem + LDS_L + bb * LBOARD);
+                constexpr int NQ = KH_PSIZE / 4;               // 1168 float4 = 9 * 128 + 16
+                float4 v[10];
+#pragma unroll
+                for (int k = 0; k < 10; ++k) {
+                    const int q = tt + 128 * k;
+                    v[k] = (q < NQ) ? L4[q] : make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
+                }
+                if (a.logits && live) {
+                    float4* lo = reinterpret_cast<float4*>(a.logits + (size_t)(b0 + bb) * KH_PSIZE);
+#pragma unroll
+                    for (int k = 0; k < 10; ++k)
+                        if (tt + 128 * k < NQ) lo[tt + 128 * k] = v[k];
+                }
+                float m = -INFINITY;
+#pragma unroll
+                for (int k = 0; k < 10; ++k) m = fmaxf(fmaxf(m, fmaxf(v[k].x, v[k].y)), fmaxf(v[k].z, v[k].w));
+                m = wave_max_f(m);
+                if (lane == 0) red[cw] = m;
+                lds_barrier();                                                              // [BS1]
+                m = fmaxf(red[bb * 2], red[bb * 2 + 1]);
+                float s = 0.0f;
+#pragma unroll
+                for (int k = 0; k < 10; ++k) {
+                    v[k].x = __expf(v[k].x - m); v[k].y = __expf(v[k].y - m);
+                    v[k].z = __expf(v[k].z - m); v[k].w = __expf(v[k].w - m);
+                    s += (v[k].x + v[k].y) + (v[k].z + v[k].w);
+                }
+                s = wave_sum_f(s);
+                if (lane == 0) red[4 + cw] = s;
+                lds_barrier();                                                              // [BS2]
+                const float inv = 1.0f / (red[4 + bb * 2] + red[4 + bb * 2 + 1]);
+                bool nan = false;
+                if (LEGAL) {
+                    // legal-move mode: the board's first wave does what gather_legal_kernel does with the stored row
+                    // (tower_mfma.hip 4d: the same operations on the same values in the same order: the same bits)
+                    nan = inv != inv;                           // a NaN logit makes the sum, hence every entry, NaN
+                    if (live && (cw & 1) == 0) {
+                        const float* Lb = reinterpret_cast<const float*>(smem + LDS_L + bb * LBOARD);
+                        const int lo = a.lg_offsets[b0 + bb], hi = a.lg_offsets[b0 + bb + 1];
+                        float sum = 0.0f;
+                        for (int k = lo + lane; k < hi; k += 64) {
+                            const int ac = a.lg_actions[k];
+                            sum += (ac >= 0 && ac < KH_PSIZE) ? __fmul_rn(__expf(Lb[ac] - m), inv) : 0.0f;
+                        }
+                        sum = wave_sum_f(sum);
+                        const float rn = sum > 0.0f ? 1.0f / sum : 0.0f;
+                        for (int k = lo + lane; k < hi; k += 64) {
+                            const int ac = a.lg_actions[k];
+                            a.lg_priors[k] = (ac >= 0 && ac < KH_PSIZE) ? __fmul_rn(__fmul_rn(__expf(Lb[ac] - m), inv), rn) : 0.0f;
+                        }
+                    }
+                } else if (live) {
+                    float4* po = reinterpret_cast<float4*>(a.policy + (size_t)(b0 + bb) * KH_PSIZE);
+#pragma unroll
+                    for (int k = 0; k < 10; ++k) {
+                        float4 o;
+                        o.x = v[k].x * inv; o.y = v[k].y * inv; o.z = v[k].z * inv; o.w = v[k].w * inv;
+                        nan |= (o.x != o.x) | (o.y != o.y) | (o.z != o.z) | (o.w != o.w);
+                        if (tt + 128 * k < NQ) {
+                            using f4 = float __attribute__((ext_vector_type(4)));
+                            const f4 ov = { o.x, o.y, o.z, o.w };
+                            __builtin_nontemporal_store(ov, reinterpret_cast<f4*>(po) + tt + 128 * k);
+                        }
+                    }
+                }
+                if (__any(nan) && lane == 0) raise_flag<LEGAL>(a, 0);
+            }
+            T8_STAMP(21);
+            lds_barrier();      // [BE] L / v64 are dead; the next group may overwrite them
+            T8_STAMP(22);
+        }
+    }
+#if KAMI_TOWER_STAMP
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    T8_STAMP(23);
+    if (lane == 0) stamps[wave * 32 + 31] = __builtin_amdgcn_s_memrealtime();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    // compute waves over the workgroup's first value row, helper waves over its second (256 floats = 4 waves x 32 stamps)
+    if (lane < 32 && (int)blockIdx.x * TW_NB + 1 < a.B)
+        reinterpret_cast<unsigned long long*>(a.vfull + ((size_t)blockIdx.x * TW_NB + (wave >> 2)) * KH_VALUE_WIDTH)[cw * 32 + lane] = stamps[wave * 32 + lane];
+#endif
+}
+
+template <typename T, int KS_STEM, bool LEGAL = false> static hipError_t launch8(const TowerArgs& a, int grid, hipStream_t s)
+{
+    constexpr int FP = KS_STEM * 16;
+    const int lds = LDS_ST + st_size(FP) + tower_par_floats(a.R) * 4 + (KAMI_TOWER_STAMP ? 16 + 8 * 32 * 8 : 0);
+    static std::atomic<bool> attr_done{ false };      // engines are called from many host threads; setting it twice is harmless
+    if (!attr_done.load(std::memory_order_acquire)) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&tower8_kernel<T, KS_STEM, LEGAL>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) return e;
+        attr_done.store(true, std::memory_order_release);
+    }
+    hipLaunchKernelGGL((tower8_kernel<T, KS_STEM, LEGAL>), dim3(grid), dim3(512), lds, s, a);
+    return hipGetLastError();
+}
+
+hipError_t launch_tower8(int dtype, int FP, const TowerArgs& a, int num_cus, hipStream_t s)
+{
+    const int ngroups = (a.B + TW_NB - 1) / TW_NB;
+    const int grid = ngroups < num_cus ? ngroups : num_cus;      // one workgroup per CU (LDS-bound residency)
+    if (a.lg_offsets) {                      // legal-move mode: compact records (F <= 32) only
+        if (FP != 32 || !a.lg_actions || !a.lg_priors || !a.lg_values || !a.lg_flags) return hipErrorInvalidValue;
+        return dtype == KH_BF16 ? launch8<__bf16, 2, true>(a, grid, s) : launch8<_Float16, 2, true>(a, grid, s);
+    }
+    if (dtype == KH_BF16) return FP == 32 ? launch8<__bf16, 2>(a, grid, s) : launch8<__bf16, 8>(a, grid, s);
+    return FP == 32 ? launch8<_Float16, 2>(a, grid, s) : launch8<_Float16, 8>(a, grid, s);
+}
+
+}  // namespace kh

@@ -8,7 +8,7 @@ from kami_amd import _lib as L, weights as W
 
 ap = argparse.ArgumentParser()
 ap.add_argument("lib"); ap.add_argument("--dtype", default="bf16"); ap.add_argument("--F", type=int, default=119); ap.add_argument("--B", type=int, default=512)
-ap.add_argument("--names", default="")
+ap.add_argument("--v8", action="store_true", help="tower8_kernel build: compute waves' stamps in the first value row, helper waves' in the second")
 a = ap.parse_args()
 lib = C.CDLL(os.path.abspath(a.lib))
 for name, (res, args) in L.SYMBOLS.items():
@@ -28,8 +28,16 @@ for _ in range(3):      # >= 2 s of back-to-back launches before the launch that
 print(f"stamped build: {ms.value * 1e3:.2f} us per launch (do not quote: shares only)")
 v = np.empty((a.B, 256), np.float32)
 lib.kh_memcpy_d2h(h, v.ctypes.data_as(C.c_void_p), d_v, v.nbytes)
-nwg = (a.B + 1) // 2
-st = v.view(np.uint64).reshape(a.B, 128)[0::2][:nwg].reshape(nwg, 4, 32).astype(np.int64)      # [wg][wave][stamp]
+nwg = a.B // 2
+rows = v.view(np.uint64).reshape(a.B, 128)
+st = rows[0::2][:nwg].reshape(nwg, 4, 32).astype(np.int64)      # [wg][wave][stamp]
+if a.v8:
+    hs = rows[1::2][:nwg].reshape(nwg, 4, 32).astype(np.int64)
+    t0 = st[:, :, 0].min(axis=1)[:, None]
+    print("helper waves, cycles since the workgroup's first compute-wave stamp (median over workgroups and waves):")
+    for k, nm in ((0, "entry"), (2, "planes half 0 converted, [B0]"), (5, "stem steps done, [B1]"), (19, "all steps done"), (21, "value fc done"), (22, "group done"), (23, "drained")):
+        print(f"   {nm:34s} {np.median(hs[:, :, k] - t0):8.0f}")
+    print("compute waves:")
 t = st[:, :, :24]
 rt = st[:, :, 31] - st[:, :, 30]
 clk = (t[:, :, 23] - t[:, :, 0]) / np.maximum(rt, 1) * 100.0
