@@ -34,9 +34,20 @@ namespace kh {
 // ---------------------------------------------------------------- ring protocol, two roles
 // Chunk c lives in slot c mod RING_D.  Step c of a compute wave multiplies chunk c (in registers since step c - 1)
 // and reads chunk c + 1 into its other register set.  Before barrier c a helper wave has waited for its two pieces of
-// chunk c + 1; after it, it refills slot (c - 1) mod RING_D — whose chunk every compute wave finished reading two
-// steps ago — with chunk c + RING_D - 1.  A chunk is requested RING_D - 2 steps before it is read.
+// chunk c + 2 (T8_LAG = 1: one chunk more than the reads that follow barrier c need), so a compute wave may read
+// chunk c + 1 BEFORE barrier c — the first step of a layer starts on operands it already holds and meets the barrier
+// in its middle (see boundary()).  After barrier c the helper refills slot (c - 1) mod RING_D — whose chunk every
+// compute wave finished reading two steps ago — with chunk c + RING_D - 1: requested RING_D - 3 steps before its
+// barrier.  Barrier c may sit anywhere between the reads of chunk c (step c - 1) and those of chunk c + 2 (step c + 1).
+constexpr int T8_LAG = 1;
+constexpr int T8_RELAX = RING_D - 2 - T8_LAG;     // steps whose waits may leave younger non-ring loads in flight
 struct CPipe { unsigned ring; int cslot; };
+
+__device__ __forceinline__ unsigned cpipe_advance(CPipe& p)      // next chunk's LDS offset, no barrier
+{
+    p.cslot = (p.cslot + 1 == RING_D) ? 0 : p.cslot + 1;
+    return p.ring + p.cslot * CHUNK;
+}
 
 __device__ __forceinline__ unsigned cpipe_step(CPipe& p)
 {
@@ -51,7 +62,7 @@ __device__ __forceinline__ unsigned cpipe_step(CPipe& p)
 template <int VMX>
 __device__ __forceinline__ void hpipe_step(Pipe& p, int hw, int lane)
 {
-    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * (RING_D - 3) + VMX) : "memory");
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * (RING_D - 3 - T8_LAG) + VMX) : "memory");
     asm volatile("s_barrier" ::: "memory");
     pipe_issue(p, hw, lane);
 }
@@ -126,6 +137,226 @@ __device__ __forceinline__ void gemm8_dummy(CPipe& p, const char* smem, int lane
     for (int f = 0; f < 8; ++f) A[PAR ^ 1][f] = *reinterpret_cast<const V*>(smem + a_off + f * 1024);
 }
 
+
+// ---------------------------------------------------------------- steps N0 .. N1-1 of a layer, operands carried by the caller
+// gemm8_layer's loop body with the register sets owned by the caller, so that a layer can be cut at its first and last
+// chunk (boundary() below).  Step n multiplies chunk n (A[cur], B[cur], cur = (PAR + n) & 1) and reads chunk n + 1.
+// BARMID: step N0's barrier sits in the MIDDLE of the step (after four MFMAs) instead of at its top — used for the step
+// that follows a boundary(), whose own barrier comes late in the layer's first chunk.
+// k-step -> byte offset of its activation fragment from b_base.  BM_RASTER / BM_CENTRE: tower_common.h's b_offset without /
+// with the centre tap first; BM_HALVES: the 33..128-plane stem, walked as two passes of 64 channels (4 k-steps per tap
+// each), the order the packer lays its weights out in.
+enum { BM_RASTER = 0, BM_CENTRE = 1, BM_HALVES = 2 };
+template <int TAPS, int KS, int BM>
+__device__ __forceinline__ constexpr unsigned b_off8(int kk, int stride)
+{
+    if (BM == BM_HALVES) {
+        const int pass = kk / (TAPS * KS / 2), k = kk % (TAPS * KS / 2);
+        return b_offset<TAPS, KS / 2, false>(k, stride) + pass * (KS / 2) * 32;
+    }
+    return b_offset<TAPS, KS, BM == BM_CENTRE>(kk, stride);
+}
+
+template <typename T, int TAPS, int KS, int MS, int PAR, int NREG, int BM, int N0, int N1, bool BARMID = false>
+__device__ __forceinline__ void gemm8_steps(CPipe& p, const char* smem, int lane, unsigned b_base, int stride,
+                                            f32x16 (&acc)[MS], typename Elem<T>::vec8 (&A)[2][8],
+                                            typename Elem<T>::vec8 (&B)[2][8 / MS],
+                                            const typename Elem<T>::vec8* breg = nullptr)
+{
+    using V = typename Elem<T>::vec8;
+    using S = LayerShape<TAPS, KS, MS>;
+    constexpr int KPC = S::KPC;
+#pragma unroll
+    for (int n = N0; n < N1; ++n) {
+        const int cur = (PAR + n) & 1, nxt = cur ^ 1;
+        if (BARMID && n == N0) {
+            static_assert(!BARMID || (MS == 2 && KPC == 4), "mid-step barrier: 2 x 4 chunk");
+            // chunk n + 1's weights landed before the PREVIOUS barrier (T8_LAG): read them first, meet the barrier
+            // after four MFMAs, read the activations behind it
+            const unsigned a_off = cpipe_advance(p) + lane * 16;
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+#pragma unroll
+                for (int ms = 0; ms < 2; ++ms) {
+                    const int i = 2 * k + ms;
+                    A[nxt][2 * i] = *reinterpret_cast<const V*>(smem + a_off + (2 * i) * 1024);
+                    A[nxt][2 * i + 1] = *reinterpret_cast<const V*>(smem + a_off + (2 * i + 1) * 1024);
+                    acc[ms] = Elem<T>::mfma(A[cur][k * MS + ms], B[cur][k], acc[ms]);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+            asm volatile("s_barrier" ::: "memory");
+#pragma unroll
+            for (int k = 2; k < 4; ++k) {
+#pragma unroll
+                for (int ms = 0; ms < 2; ++ms) {
+                    if (k == 2 && n + 1 < S::NCH) {
+#pragma unroll
+                        for (int j = 0; j < 2; ++j) {
+                            const int kk = 2 * ms + j;
+                            if ((n + 1) * KPC + kk < NREG) B[nxt][kk] = breg[(n + 1) * KPC + kk];
+                            else B[nxt][kk] = *reinterpret_cast<const V*>(smem + b_base + b_off8<TAPS, KS, BM>((n + 1) * KPC + kk, stride));
+                        }
+                    }
+                    acc[ms] = Elem<T>::mfma(A[cur][k * MS + ms], B[cur][k], acc[ms]);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+            continue;
+        }
+        const unsigned a_off = cpipe_step(p) + lane * 16;
+#pragma unroll
+        for (int f = 0; f < 8; ++f) A[nxt][f] = *reinterpret_cast<const V*>(smem + a_off + f * 1024);
+        if (n + 1 < S::NCH) {
+#pragma unroll
+            for (int k = 0; k < KPC; ++k) {
+                if ((n + 1) * KPC + k < NREG) B[nxt][k] = breg[(n + 1) * KPC + k];
+                else B[nxt][k] = *reinterpret_cast<const V*>(smem + b_base + b_off8<TAPS, KS, BM>((n + 1) * KPC + k, stride));
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < KPC; ++k)
+#pragma unroll
+            for (int ms = 0; ms < MS; ++ms) acc[ms] = Elem<T>::mfma(A[cur][k * MS + ms], B[cur][k], acc[ms]);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);   // DS read
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // MFMA
+        }
+    }
+}
+
+// ---------------------------------------------------------------- layer boundary
+// What ends layer L (a 2 x 4 chunk: stem or 3x3) and starts the 3x3 layer L + 1, as ONE scheduled sequence:
+//   L's last chunk tile-major (tile 0's sums final four MFMAs early) | L + 1's first chunk — the centre tap, whose
+//   operand is this wave's own output, straight from the epilogue's registers — with L's epilogue spread over the
+//   gaps of both, the image write-back for the neighbours' taps behind it, and L + 1's barrier only before the first
+//   reads of that image (chunk 1's activations).
+// The matrix pipe therefore never waits for "epilogue -> LDS -> barrier -> read": measured on tower8 v1 that wait
+// was ~435 cycles per conv1 -> conv2 boundary and ~775 per conv2 -> conv1 (profiles/r03_tower8_v1_ab_stamps.txt).
+// Every micro-block below is fenced (sched_barrier): source order IS issue order.
+//   EPI_PACK   t = relu(acc), rounded to T first   (nn.cpp:30)
+//   EPI_RESID  x = x + relu(acc)                   (nn.cpp:31; with x = 0 also the stem's relu, nn.cpp:65)
+// Same operations on the same values as epilogue_pack / epilogue_residual: the same bits.
+enum { EPI_STEM = 0, EPI_PACK = 1, EPI_RESID = 2 };
+
+template <typename T, int EPI, int G>
+__device__ __forceinline__ u32x2 epi_group(const f32x16& acc, f32x16& xf)
+{
+    u32x2 o;
+    if (EPI == EPI_PACK) {
+        o.x = relu_pk(pack2<T>(acc[4 * G + 0], acc[4 * G + 1]));
+        o.y = relu_pk(pack2<T>(acc[4 * G + 2], acc[4 * G + 3]));
+    } else {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const float t = relu_nan(acc[4 * G + i]);
+            xf[4 * G + i] = EPI == EPI_RESID ? xf[4 * G + i] + t : t;
+        }
+        o.x = pack2<T>(xf[4 * G + 0], xf[4 * G + 1]);
+        o.y = pack2<T>(xf[4 * G + 2], xf[4 * G + 3]);
+    }
+    return o;
+}
+
+#define T8_FENCE() __builtin_amdgcn_sched_barrier(0)
+
+// CURP: register set that holds L's last chunk (A[CURP], B[CURP]); on exit A[CURP] / B[CURP] hold L + 1's chunk 1 and
+// nacc L + 1's sums after its chunk 0.  out_pix: LDS offset of the lane's own pixel (+ 8 h: its channel group) in the
+// image L + 1 reads; nb_base: L + 1's b_base; nshift: LDS offset of L + 1's folded shifts (+ 16 h).  All three are
+// per-lane bases that every access below extends by an immediate only.
+template <typename T, int EPI, int CURP>
+__device__ __forceinline__ void boundary(CPipe& p, char* smem, int lane, f32x16 (&acc)[2], f32x16 (&nacc)[2],
+                                         unsigned nshift, typename Elem<T>::vec8 (&A)[2][8],
+                                         typename Elem<T>::vec8 (&B)[2][4], f32x16 (&xf)[2], unsigned out_pix, unsigned nb_base)
+{
+    using V = typename Elem<T>::vec8;
+    constexpr int cur = CURP, nxt = CURP ^ 1;
+    u32x2 o[2][4];
+#define T8_LDN(ms, g) do { const float4 s_ = *reinterpret_cast<const float4*>(smem + nshift + ((ms) * 32 + 8 * (g)) * 4); \
+        nacc[ms][4 * (g) + 0] = s_.x; nacc[ms][4 * (g) + 1] = s_.y; nacc[ms][4 * (g) + 2] = s_.z; nacc[ms][4 * (g) + 3] = s_.w; } while (0)
+#define T8_ST(t, g) (*reinterpret_cast<u32x2*>(smem + out_pix + ((t) * 32 + 8 * (g)) * 2) = o[t][g])
+#define T8_FRAG(ks) __builtin_bit_cast(V, (u32x4){ o[(ks) >> 1][2 * ((ks) & 1)].x, o[(ks) >> 1][2 * ((ks) & 1)].y, \
+                                                   o[(ks) >> 1][2 * ((ks) & 1) + 1].x, o[(ks) >> 1][2 * ((ks) & 1) + 1].y })
+    const unsigned a_off = cpipe_step(p) + lane * 16;                                   // [barrier: L's last step]
+#define T8_RDA(set, f, off) (A[set][f] = *reinterpret_cast<const V*>(smem + (off) + (f) * 1024))
+    // ---- L's last chunk, tile 0; L + 1's shifts become its accumulators' initial values
+    T8_LDN(0, 0); T8_LDN(0, 1); acc[0] = Elem<T>::mfma(A[cur][0], B[cur][0], acc[0]); T8_FENCE();
+    T8_LDN(0, 2); T8_LDN(0, 3); acc[0] = Elem<T>::mfma(A[cur][2], B[cur][1], acc[0]); T8_FENCE();
+    T8_LDN(1, 0); T8_LDN(1, 1); acc[0] = Elem<T>::mfma(A[cur][4], B[cur][2], acc[0]); T8_FENCE();
+    T8_LDN(1, 2); T8_LDN(1, 3); acc[0] = Elem<T>::mfma(A[cur][6], B[cur][3], acc[0]); T8_FENCE();
+    // ---- tile 1; L + 1's first weights; tile 0's epilogue once its sums are final
+    T8_RDA(nxt, 0, a_off); T8_RDA(nxt, 1, a_off); acc[1] = Elem<T>::mfma(A[cur][1], B[cur][0], acc[1]); T8_FENCE();
+    T8_RDA(nxt, 2, a_off); T8_RDA(nxt, 3, a_off); acc[1] = Elem<T>::mfma(A[cur][3], B[cur][1], acc[1]); T8_FENCE();
+    T8_RDA(nxt, 4, a_off); T8_RDA(nxt, 5, a_off);
+    o[0][0] = epi_group<T, EPI, 0>(acc[0], xf[0]); o[0][1] = epi_group<T, EPI, 1>(acc[0], xf[0]);
+    acc[1] = Elem<T>::mfma(A[cur][5], B[cur][2], acc[1]); T8_FENCE();
+    T8_RDA(nxt, 6, a_off); T8_RDA(nxt, 7, a_off);
+    o[0][2] = epi_group<T, EPI, 2>(acc[0], xf[0]); o[0][3] = epi_group<T, EPI, 3>(acc[0], xf[0]);
+    acc[1] = Elem<T>::mfma(A[cur][7], B[cur][3], acc[1]); T8_FENCE();
+    // ---- L + 1, chunk 0: centre tap, k-steps 0..3 = the wave's own channels 0..15, .., 48..63
+    const unsigned a2 = cpipe_advance(p) + lane * 16;             // chunk 1's weights: landed before the barrier above
+    {
+        const V f0 = T8_FRAG(0);
+        T8_ST(0, 0); T8_ST(0, 1); T8_RDA(cur, 0, a2);
+        nacc[0] = Elem<T>::mfma(A[nxt][0], f0, nacc[0]); T8_FENCE();
+        T8_ST(0, 2); T8_ST(0, 3); T8_RDA(cur, 1, a2);
+        nacc[1] = Elem<T>::mfma(A[nxt][1], f0, nacc[1]); T8_FENCE();
+    }
+    {
+        const V f1 = T8_FRAG(1);
+        T8_RDA(cur, 2, a2); T8_RDA(cur, 3, a2);
+        nacc[0] = Elem<T>::mfma(A[nxt][2], f1, nacc[0]); T8_FENCE();
+        T8_RDA(cur, 4, a2); T8_RDA(cur, 5, a2);
+        o[1][0] = epi_group<T, EPI, 0>(acc[1], xf[1]); o[1][1] = epi_group<T, EPI, 1>(acc[1], xf[1]);
+        nacc[1] = Elem<T>::mfma(A[nxt][3], f1, nacc[1]); T8_FENCE();
+    }
+    {
+        const V f2 = T8_FRAG(2);
+        o[1][2] = epi_group<T, EPI, 2>(acc[1], xf[1]); o[1][3] = epi_group<T, EPI, 3>(acc[1], xf[1]);
+        T8_ST(1, 0); T8_ST(1, 1); T8_ST(1, 2); T8_ST(1, 3);
+        nacc[0] = Elem<T>::mfma(A[nxt][4], f2, nacc[0]); T8_FENCE();
+        T8_RDA(cur, 6, a2); T8_RDA(cur, 7, a2);
+        nacc[1] = Elem<T>::mfma(A[nxt][5], f2, nacc[1]); T8_FENCE();
+    }
+    {
+        const V f3 = T8_FRAG(3);
+        // the image writes are older than the two reads above: done once at most two LDS operations are outstanding;
+        // then every wave's are, and chunk 1's activations (the window's first tap) may be read      [barrier: L + 1's first step]
+        asm volatile("s_waitcnt lgkmcnt(2)\n\ts_barrier" ::: "memory");
+#pragma unroll
+        for (int k = 0; k < 4; ++k) B[cur][k] = *reinterpret_cast<const V*>(smem + nb_base + b_offset<9, TW_CP / 16, true>(4 + k, XSTR));
+        nacc[0] = Elem<T>::mfma(A[nxt][6], f3, nacc[0]); T8_FENCE();
+        nacc[1] = Elem<T>::mfma(A[nxt][7], f3, nacc[1]); T8_FENCE();
+    }
+#undef T8_LDN
+#undef T8_ST
+}
+
+// The last 3x3 layer's (or, without blocks, the stem's) end in front of the heads: last chunk tile-major, the whole
+// epilogue, no image (both heads are 1x1 and read the wave's own tile).  A[CURP ^ 1] receives policyconv's first chunk.
+template <typename T, int EPI, int CURP>
+__device__ __forceinline__ void tower_tail(CPipe& p, const char* smem, int lane, f32x16 (&acc)[2], typename Elem<T>::vec8 (&A)[2][8],
+                                           typename Elem<T>::vec8 (&B)[2][4], f32x16 (&xf)[2], Packed<2>& xk)
+{
+    using V = typename Elem<T>::vec8;
+    constexpr int cur = CURP, nxt = CURP ^ 1;
+    const unsigned a_off = cpipe_step(p) + lane * 16;
+    T8_RDA(nxt, 0, a_off); T8_RDA(nxt, 1, a_off); acc[0] = Elem<T>::mfma(A[cur][0], B[cur][0], acc[0]); T8_FENCE();
+    T8_RDA(nxt, 2, a_off); T8_RDA(nxt, 3, a_off); acc[0] = Elem<T>::mfma(A[cur][2], B[cur][1], acc[0]); T8_FENCE();
+    T8_RDA(nxt, 4, a_off); T8_RDA(nxt, 5, a_off); acc[0] = Elem<T>::mfma(A[cur][4], B[cur][2], acc[0]); T8_FENCE();
+    T8_RDA(nxt, 6, a_off); T8_RDA(nxt, 7, a_off); acc[0] = Elem<T>::mfma(A[cur][6], B[cur][3], acc[0]); T8_FENCE();
+    acc[1] = Elem<T>::mfma(A[cur][1], B[cur][0], acc[1]); T8_FENCE();
+    acc[1] = Elem<T>::mfma(A[cur][3], B[cur][1], acc[1]); T8_FENCE();
+    xk.o[0][0] = epi_group<T, EPI, 0>(acc[0], xf[0]); xk.o[0][1] = epi_group<T, EPI, 1>(acc[0], xf[0]);
+    acc[1] = Elem<T>::mfma(A[cur][5], B[cur][2], acc[1]); T8_FENCE();
+    xk.o[0][2] = epi_group<T, EPI, 2>(acc[0], xf[0]); xk.o[0][3] = epi_group<T, EPI, 3>(acc[0], xf[0]);
+    acc[1] = Elem<T>::mfma(A[cur][7], B[cur][3], acc[1]); T8_FENCE();
+    xk.o[1][0] = epi_group<T, EPI, 0>(acc[1], xf[1]); xk.o[1][1] = epi_group<T, EPI, 1>(acc[1], xf[1]);
+    xk.o[1][2] = epi_group<T, EPI, 2>(acc[1], xf[1]); xk.o[1][3] = epi_group<T, EPI, 3>(acc[1], xf[1]);
+}
+#undef T8_RDA
+
 // zero the halo pixels of the two images of `stride` bytes per pixel at `base` (256 threads)
 template <int STRIDE>
 __device__ __forceinline__ void zero_halo(char* base, int board_bytes, int t)
@@ -154,7 +385,7 @@ __global__ __launch_bounds__(512) void tower8_kernel(TowerArgs a)
     constexpr int LDS_L = LDS_X;
     using V = typename Elem<T>::vec8;
     // steps (= chunks = barriers) per board group, phase by phase: both roles walk exactly these
-    constexpr int NSTEM = KS_STEM == 8 ? 2 * LayerShape<9, 4, 2>::NCH : LayerShape<9, KS_STEM, 2>::NCH;
+    constexpr int NSTEM = LayerShape<9, KS_STEM, 2>::NCH;     // (33..128 planes: 2 x 9 chunks, the two 64-channel passes)
     constexpr int P1 = NSTEM & 1;                            // register-set parity after the stem
     constexpr int NLAYER = LayerShape<9, TW_CP / 16, 2>::NCH;                                   // 9 per 3x3 layer
     constexpr int NPOL = LayerShape<1, TW_CP / 16, 4>::NCH + LayerShape<1, KH_POLICY_MID / 16, 4>::NCH + (P1 ? 1 : 0);
@@ -223,12 +454,12 @@ __global__ __launch_bounds__(512) void tower8_kernel(TowerArgs a)
                 lds_barrier();                                                              // [B0]
                 first = false;
                 T8_STAMP(2);
-                // pass 1's first RING_D - 2 steps need chunks requested before the second half's loads
+                // pass 1's first T8_RELAX steps wait for chunks requested before the second half's loads
 #pragma unroll
-                for (int i = 0; i < RING_D - 2; ++i) hpipe_step<8>(pipe, cw, lane);
+                for (int i = 0; i < T8_RELAX; ++i) hpipe_step<8>(pipe, cw, lane);
                 ingest_half<T>(pl[1], 1, smem + LDS_ST, SSTR, SBOARD, b0, ct, lane, a);
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                for (int i = RING_D - 2; i < NSTEM; ++i) hpipe_step<0>(pipe, cw, lane);
+                for (int i = T8_RELAX; i < NSTEM; ++i) hpipe_step<0>(pipe, cw, lane);
             } else {
                 if (first) {
 #pragma unroll
@@ -304,10 +535,9 @@ __global__ __launch_bounds__(512) void tower8_kernel(TowerArgs a)
                 T8_STAMP(2);
                 for (int i = 0; i < NSTEM; ++i) hpipe_step<0>(pipe, cw, lane);
             }
-            asm volatile("s_barrier" ::: "memory");                                         // [B1]
             T8_STAMP(5);
             // tower + policy steps.  In the first group the valuefc row is requested here: 17 loads younger than
-            // the ring's, which the next RING_D - 2 steps' waits leave in flight.
+            // the ring's, which the next T8_RELAX steps' waits leave in flight.
             int relax = 0;
             if (grp == (int)blockIdx.x) {
 #pragma unroll
@@ -315,12 +545,18 @@ __global__ __launch_bounds__(512) void tower8_kernel(TowerArgs a)
                     fcw[k] = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(a.fcw4) + (size_t)k * KH_VALUE_WIDTH * 16 + (unsigned)ct * 16u);
                 fcbias = a.fcb[ct];
                 __builtin_amdgcn_sched_barrier(0);
-                relax = RING_D - 2;
+                relax = T8_RELAX;
             }
             const int nsteps = 2 * R * NLAYER + NPOL;
             for (int i = 0; i < nsteps; ++i) {
                 if (relax > 0) { hpipe_step<17>(pipe, cw, lane); --relax; }
                 else hpipe_step<0>(pipe, cw, lane);
+                if (i == 0 && R > 0) {
+                    // behind the first tower step's barrier every compute wave's last read of S is complete: T, which
+                    // shares LDS with S, gets its zero halo, nine steps before conv2 of the first block reads through it
+                    zero_halo<XSTR>(smem + LDS_ST, XBOARD, ct);
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                }
             }
             T8_STAMP(19);
             asm volatile("s_barrier" ::: "memory");                                         // [BL] logits in LDS; v64 since 4a
@@ -370,6 +606,10 @@ __global__ __launch_bounds__(512) void tower8_kernel(TowerArgs a)
         const unsigned sin = LDS_ST + wb * SBOARD + (py * PITCH + px) * SSTR + h * 16;
         const unsigned xout = LDS_X + wb * XBOARD + ((py + 1) * PITCH + px + 1) * XSTR;     // own pixel
         const unsigned tout = LDS_ST + wb * XBOARD + ((py + 1) * PITCH + px + 1) * XSTR;
+        // per-lane bases of the boundary's accesses (opaque to the optimiser: it would otherwise fold each access's
+        // constant into an address register of its own, dozens of them, and spill)
+        unsigned xout_h = xout + 8 * h, tout_h = tout + 8 * h, sh0 = LDS_PAR + 16 * h;
+        asm volatile("" : "+v"(xout_h), "+v"(tout_h), "+v"(sh0));
 
         CPipe pipe;
         pipe.ring = LDS_RING; pipe.cslot = 0;
@@ -397,50 +637,37 @@ __global__ __launch_bounds__(512) void tower8_kernel(TowerArgs a)
             // the centre-tap operand of the next conv and the input of both heads; X carries it for the neighbours' taps.
             Packed<2> xk;
             f32x16 xf[2];          // the same tile in fp32: the skip operand and the value head's input
+#pragma unroll
+            for (int i = 0; i < 16; ++i) { xf[0][i] = 0.0f; xf[1][i] = 0.0f; }
             T8_STAMP(3);
-            // ---- stem: conv1 + batchnorm1 + relu, S -> X                           nn.cpp:62-65
+            // ---- stem: conv1 + batchnorm1 + relu, S -> X (nn.cpp:62-65): all but its last chunk
+            f32x16 accA[2], accB[2];       // the running layer's sums / the next layer's (alternating roles)
+            V B[2][4];
+            acc_init<2>(accA, shift3, h);
             {
-                f32x16 acc[2];
-                acc_init<2>(acc, shift3, h);
-                if (KS_STEM == 8) {
-                    gemm8_layer<T, 9, 4, 2, 0>(pipe, smem, lane, sin, SSTR, acc, A);            // planes 0..63
-                    gemm8_layer<T, 9, 4, 2, 1>(pipe, smem, lane, sin + 128, SSTR, acc, A);      // planes 64..127
-                } else {
-                    gemm8_layer<T, 9, KS_STEM, 2, 0>(pipe, smem, lane, sin, SSTR, acc, A);
-                }
-                T8_STAMP(4);
-                epilogue_residual<T, false>(acc, xf, xk);
-                store_packed<2>(xk, smem, xout, h);
-                lds_barrier();                                                              // [B1]
-                // T shares LDS with S: clear T's halo before the tower reads through it
-                zero_halo<XSTR>(smem + LDS_ST, XBOARD, ct);
+                // 33..128 planes: two passes of 64 channels (planes 0..63, then 64..127), one 18-chunk walk
+                constexpr int BMS = KS_STEM == 8 ? BM_HALVES : BM_RASTER;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) B[0][k] = *reinterpret_cast<const V*>(smem + sin + b_off8<9, KS_STEM, BMS>(k, SSTR));
+                gemm8_steps<T, 9, KS_STEM, 2, 0, 0, BMS, 0, NSTEM - 1>(pipe, smem, lane, sin, SSTR, accA, A, B);
             }
-            T8_STAMP(5);
-
+            T8_STAMP(4);
+            // (T shares LDS with S and the tower's image reads go through T's halo: the helper waves clear it behind the
+            //  first tower step's barrier, after every wave's last read of S and long before conv2 of the first block.)
+            constexpr int CP1 = P1 ^ 1;      // register set of the last chunk of the stem and of every conv2
             // ---- residual tower: x = x + relu(bn2(conv2(relu(bn1(conv1 x)))))   nn.cpp:26-34
-            f32x16 accn[2];         // next layer's accumulator start (its folded shifts), fetched a layer ahead
-            acc_init<2>(accn, shift3 + TW_CP, h);
+            // The stem's end is a residual end with x = 0 (0 + relu(acc) = relu(acc) exactly): ONE boundary form at the
+            // loop's top, one tail behind it, no branch inside.
+            T8_STAMP(5);
             for (int r = 0; r < R; ++r) {
-                f32x16 acc[2];
-                V bf[4];
-                packed_fragments<T, 2>(xk, bf);
-                acc[0] = accn[0]; acc[1] = accn[1];
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");          // own image writes done before the step barrier
-                acc_init<2>(accn, shift3 + (2 + 2 * r) * TW_CP, h);
-                gemm8_layer<T, 9, TW_CP / 16, 2, P1, 4, true, 6>(pipe, smem, lane, xin, XSTR, acc, A, bf);
+                boundary<T, EPI_RESID, CP1>(pipe, smem, lane, accA, accB, sh0 + (1 + 2 * r) * TW_CP * 4, A, B, xf, xout_h, xin);
+                gemm8_steps<T, 9, TW_CP / 16, 2, P1, 4, BM_CENTRE, 1, 8, true>(pipe, smem, lane, xin, XSTR, accB, A, B);        // conv1
                 T8_STAMP(6 + 2 * r);
-                Packed<2> tk;
-                epilogue_pack<T, 2>(acc, tk);
-                store_packed<2>(tk, smem, tout, h);
-                packed_fragments<T, 2>(tk, bf);
-                acc[0] = accn[0]; acc[1] = accn[1];
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                acc_init<2>(accn, shift3 + (3 + 2 * r) * TW_CP, h);         // (past the last block: the policy shifts, unused)
-                gemm8_layer<T, 9, TW_CP / 16, 2, P1 ^ 1, 4, true, 11>(pipe, smem, lane, tin, XSTR, acc, A, bf);
+                boundary<T, EPI_PACK, P1>(pipe, smem, lane, accB, accA, sh0 + (2 + 2 * r) * TW_CP * 4, A, B, xf, tout_h, tin);
+                gemm8_steps<T, 9, TW_CP / 16, 2, P1 ^ 1, 4, BM_CENTRE, 1, 8, true>(pipe, smem, lane, tin, XSTR, accA, A, B);    // conv2
                 T8_STAMP(7 + 2 * r);
-                epilogue_residual<T, true>(acc, xf, xk);
-                store_packed<2>(xk, smem, xout, h);
             }
+            tower_tail<T, EPI_RESID, CP1>(pipe, smem, lane, accA, A, B, xf, xk);
 
             // ---- value head, first half: valueconv + vbatchnorm + relu (nn.cpp:83-85) on the fp32 tile (see
             //      tower_mfma.hip 4a: four partial sums, halves joined by one v_permlane32_swap; a NaN or Inf anywhere
