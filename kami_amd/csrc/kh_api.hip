@@ -123,7 +123,7 @@ struct Weights {
     std::vector<kh::SimpleLayer> layers; // stem, 2R tower convs, policyconv, policyconv2, valueconv
     const float *fcw = nullptr, *fcb = nullptr;
     // whole-network MFMA kernel (tower_mfma.hip): packed fragment stream + folded parameters
-    DevMem tw_stream, tw_par, tw_fc4;
+    DevMem tw_stream, tw_stream8, tw_par, tw_fc4;      // tw_stream8: the stream in tower8_kernel's stem order (empty: same as tw_stream)
     int tw_nchunks = 0, tw_npar = 0, tw_FP = 0;
     bool tw_ok = false;
     std::string tw_why;
@@ -176,7 +176,7 @@ uint16_t f2f16(float f)
 // packed_fragments): slot (h, j) of k-step ks is input channel
 // 32 (ks >> 1) + 8 (2 (ks & 1) + (j >> 2)) + 4 h + (j & 3) instead of 16 ks + 8 h + j.
 void pack_layer(std::vector<uint16_t>& out, int dtype, const float* w, const float* scale, int Co, int Ci,
-                int taps, int KS, int MS, int ci0 = 0, bool centre_first = false, int perm = 0)
+                int taps, int KS, int MS, int ci0 = 0, bool centre_first = false, int perm = 0, bool pad = true)
 {
     int kstep = 0;
     for (int ti = 0; ti < taps; ++ti) {
@@ -195,7 +195,7 @@ void pack_layer(std::vector<uint16_t>& out, int dtype, const float* w, const flo
                     }
                 }
     }
-    while (out.size() % 4096) out.push_back(0);
+    while (pad && out.size() % 4096) out.push_back(0);
 }
 
 // Fragments of one layer for layers_mfma.hip, BN scale folded in: 8 KB chunks of 64 input channels x 64
@@ -372,12 +372,14 @@ int build_tower(Weights& W, const HostNet& n, int dtype, int F, int C, int R)
     const int FP = F <= 32 ? 32 : 128;
     if (tower_lds_bytes(FP, R) > 160 * 1024) { W.tw_why = "too many residual blocks for the LDS parameter area"; return KH_OK; }
     std::vector<float> sc(128), sh(128);
-    std::vector<uint16_t> stream;
+    std::vector<uint16_t> stream, stem8;
     std::vector<float> par((size_t)tower_par_copy_floats(R), 0.0f);
     fold_bn(n.stem, C, sc.data(), sh.data());
     if (FP == 128) {        // two 64-plane passes: the second half of the planes is still arriving during the first
         pack_layer(stream, dtype, n.stem.w, sc.data(), C, F, 9, 4, 2, 0);
         pack_layer(stream, dtype, n.stem.w, sc.data(), C, F, 9, 4, 2, 64);
+        // tower8_kernel: four 32-plane passes in one unpadded run of 72 k-steps = the same 18 chunks
+        for (int q = 0; q < 4; ++q) pack_layer(stem8, dtype, n.stem.w, sc.data(), C, F, 9, 2, 2, 32 * q, false, 0, false);
     } else {
         pack_layer(stream, dtype, n.stem.w, sc.data(), C, F, 9, FP / 16, 2);
     }
@@ -414,6 +416,12 @@ int build_tower(Weights& W, const HostNet& n, int dtype, int F, int C, int R)
     rc |= W.tw_fc4.ensure(fc4.size() * 4);
     if (rc) return KH_ERR_HIP;
     HIPCHK(hipMemcpy(W.tw_stream.p, stream.data(), stream.size() * 2, hipMemcpyHostToDevice));
+    if (!stem8.empty()) {
+        if (stem8.size() != (size_t)18 * 4096 || stem8.size() > stream.size()) return fail(KH_ERR_INVALID, "internal: stem stream size");
+        memcpy(stream.data(), stem8.data(), stem8.size() * 2);          // everything behind the stem is the same
+        if (W.tw_stream8.ensure(stream.size() * 2)) return KH_ERR_HIP;
+        HIPCHK(hipMemcpy(W.tw_stream8.p, stream.data(), stream.size() * 2, hipMemcpyHostToDevice));
+    }
     HIPCHK(hipMemcpy(W.tw_par.p, par.data(), par.size() * 4, hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(W.tw_fc4.p, fc4.data(), fc4.size() * 4, hipMemcpyHostToDevice));
     W.tw_ok = true;
@@ -627,6 +635,12 @@ int forward_simple(kh_engine* e, const Weights& W, Slot& s, const float* d_in, i
 // The throughput path: one persistent kernel for the whole forward pass (tower_mfma.hip).
 struct LegalDev { const int32_t* offsets; const int32_t* actions; float* priors; float* values; int* flags; };
 
+// the weight stream in the running tower kernel's stem order (kh_internal.h: tower_variant)
+static const char* tower_stream(const Weights& W)
+{
+    return kh::tower_variant() == 8 && W.tw_stream8.p ? W.tw_stream8.as<char>() : W.tw_stream.as<char>();
+}
+
 int forward_tower(kh_engine* e, const Weights& W, Slot& s, const float* d_in, int B,
                   float* d_policy, float* d_vfull, float* d_logits_out, const kh_board* d_boards = nullptr,
                   const LegalDev* lg = nullptr)
@@ -641,7 +655,7 @@ int forward_tower(kh_engine* e, const Weights& W, Slot& s, const float* d_in, in
     }
     kh::TowerArgs a;
     a.in = d_in; a.boards = d_boards; a.B = B; a.F = e->cfg.features; a.R = e->cfg.residuals;
-    a.wstream = W.tw_stream.as<char>(); a.nchunks = W.tw_nchunks;
+    a.wstream = tower_stream(W); a.nchunks = W.tw_nchunks;
     a.params = W.tw_par.as<float>(); a.npar = W.tw_npar;
     a.fcw4 = W.tw_fc4.as<float>(); a.fcb = W.tw_fc4.as<float>() + (size_t)KH_VALUE_WIDTH * 64;
     a.policy = d_policy; a.vfull = d_vfull; a.logits = d_logits_out; a.flags = flags;
@@ -765,7 +779,7 @@ int infer_host_pinned(kh_engine* e, const Weights& W, Slot& s, const float* inpu
         HIPCHK(hipMemcpyAsync(d_in + (size_t)lo * 64 * F, input + (size_t)lo * 64 * F, (size_t)n * 64 * F * 4, hipMemcpyHostToDevice, q));
         kh::TowerArgs a;
         a.in = d_in + (size_t)lo * 64 * F; a.boards = nullptr; a.B = n; a.F = e->cfg.features; a.R = e->cfg.residuals;
-        a.wstream = W.tw_stream.as<char>(); a.nchunks = W.tw_nchunks;
+        a.wstream = tower_stream(W); a.nchunks = W.tw_nchunks;
         a.params = W.tw_par.as<float>(); a.npar = W.tw_npar;
         a.fcw4 = W.tw_fc4.as<float>(); a.fcb = W.tw_fc4.as<float>() + (size_t)KH_VALUE_WIDTH * 64;
         a.policy = d_pol + (size_t)lo * KH_PSIZE; a.vfull = d_vf + (size_t)lo * KH_VALUE_WIDTH; a.logits = nullptr; a.flags = flags;

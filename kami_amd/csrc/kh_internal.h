@@ -75,6 +75,9 @@ hipError_t launch_tower(int dtype, int FP, const TowerArgs& a, int num_cus, hipS
 // tower8_mfma.hip: the same forward with specialised waves (4 compute + 4 helper waves per workgroup); launch_tower
 // dispatches to it (KAMI_TOWER_V=4|8 overrides the build's default for A/B runs)
 hipError_t launch_tower8(int dtype, int FP, const TowerArgs& a, int num_cus, hipStream_t s);
+// 4 or 8: which of the two launch_tower runs.  They walk a 33..128-plane stem in different orders (two passes of 64
+// planes / four of 32), so TowerArgs::wstream must be the stream packed for the running one.
+int tower_variant();
 
 // ---- layers_mfma.hip ----------------------------------------------------------------------
 // bf16 / f16 path for wide nets (65..256 filters): one MFMA kernel launch per layer.

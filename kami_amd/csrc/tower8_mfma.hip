@@ -29,6 +29,12 @@
 #define T8_STAMP(k) do { } while (0)
 #endif
 
+// Timing-only ablations (diagnostic builds, -DKAMI_TOWER8_ABL=<bits>; results are NOT the network's): 1 no LDS-DMA in the
+// steps (the ring keeps its first chunks), 2 no activation reads in the regular steps, 4 no weight reads in them.
+#ifndef KAMI_TOWER8_ABL
+#define KAMI_TOWER8_ABL 0
+#endif
+
 namespace kh {
 
 // ---------------------------------------------------------------- ring protocol, two roles
@@ -40,7 +46,6 @@ namespace kh {
 // compute wave finished reading two steps ago — with chunk c + RING_D - 1: requested RING_D - 3 steps before its
 // barrier.  Barrier c may sit anywhere between the reads of chunk c (step c - 1) and those of chunk c + 2 (step c + 1).
 constexpr int T8_LAG = 1;
-constexpr int T8_RELAX = RING_D - 2 - T8_LAG;     // steps whose waits may leave younger non-ring loads in flight
 struct CPipe { unsigned ring; int cslot; };
 
 __device__ __forceinline__ unsigned cpipe_advance(CPipe& p)      // next chunk's LDS offset, no barrier
@@ -58,13 +63,33 @@ __device__ __forceinline__ unsigned cpipe_step(CPipe& p)
     return p.ring + p.cslot * CHUNK;
 }
 
-// VMX: vector-memory operations of this helper wave that are YOUNGER than the ring's and may stay in flight
+// A stream wave's half of a chunk: four 1 KB LDS-DMA pieces (tower_common.h's pipe_issue moves a quarter).
+__device__ __forceinline__ void pipe_issue4(Pipe& p, int hw, int lane)
+{
+    const char* sbase = p.stream + (size_t)p.next * CHUNK + hw * 4096;      // wave-uniform -> SGPR pair
+    const unsigned dst = p.ring + p.islot * CHUNK + hw * 4096;
+    const unsigned voff = lane * 16;
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\t"
+                 "global_load_lds_dwordx4 %1, %2\n\tglobal_load_lds_dwordx4 %1, %2 offset:1024\n\t"
+                 "global_load_lds_dwordx4 %1, %2 offset:2048\n\tglobal_load_lds_dwordx4 %1, %2 offset:3072\n\t"
+                 "s_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(voff), "s"(sbase), "s"(dst) : "memory");
+    p.next = (p.next + 1 == p.nch) ? 0 : p.next + 1;
+    p.islot = (p.islot + 1 == RING_D) ? 0 : p.islot + 1;
+}
+
+// VMX: vector-memory operations of this stream wave that are YOUNGER than the ring's and may stay in flight
 template <int VMX>
 __device__ __forceinline__ void hpipe_step(Pipe& p, int hw, int lane)
 {
-    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * (RING_D - 3 - T8_LAG) + VMX) : "memory");
+#if KAMI_TOWER8_ABL & 1
     asm volatile("s_barrier" ::: "memory");
-    pipe_issue(p, hw, lane);
+#else
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 * (RING_D - 3 - T8_LAG) + VMX) : "memory");
+    asm volatile("s_barrier" ::: "memory");
+    pipe_issue4(p, hw, lane);
+#endif
 }
 
 // ---------------------------------------------------------------- implicit-GEMM layer, compute-wave side
@@ -144,15 +169,20 @@ __device__ __forceinline__ void gemm8_dummy(CPipe& p, const char* smem, int lane
 // BARMID: step N0's barrier sits in the MIDDLE of the step (after four MFMAs) instead of at its top — used for the step
 // that follows a boundary(), whose own barrier comes late in the layer's first chunk.
 // k-step -> byte offset of its activation fragment from b_base.  BM_RASTER / BM_CENTRE: tower_common.h's b_offset without /
-// with the centre tap first; BM_HALVES: the 33..128-plane stem, walked as two passes of 64 channels (4 k-steps per tap
-// each), the order the packer lays its weights out in.
-enum { BM_RASTER = 0, BM_CENTRE = 1, BM_HALVES = 2 };
+// with the centre tap first; BM_HALVES / BM_QUARTERS: the 33..128-plane stem walked as two passes of 64 channels
+// (tower_mfma.hip's order) / four passes of 32 (this kernel's: the planes arrive and are converted quarter by quarter),
+// the order the packer lays the stream's weights out in.
+enum { BM_RASTER = 0, BM_CENTRE = 1, BM_HALVES = 2, BM_QUARTERS = 3 };
 template <int TAPS, int KS, int BM>
 __device__ __forceinline__ constexpr unsigned b_off8(int kk, int stride)
 {
-    if (BM == BM_HALVES) {
+    if constexpr (BM == BM_HALVES) {
         const int pass = kk / (TAPS * KS / 2), k = kk % (TAPS * KS / 2);
         return b_offset<TAPS, KS / 2, false>(k, stride) + pass * (KS / 2) * 32;
+    }
+    if constexpr (BM == BM_QUARTERS) {
+        const int pass = kk / (TAPS * KS / 4), k = kk % (TAPS * KS / 4);
+        return b_offset<TAPS, KS / 4, false>(k, stride) + pass * (KS / 4) * 32;
     }
     return b_offset<TAPS, KS, BM == BM_CENTRE>(kk, stride);
 }
@@ -206,11 +236,15 @@ __device__ __forceinline__ void gemm8_steps(CPipe& p, const char* smem, int lane
         }
         const unsigned a_off = cpipe_step(p) + lane * 16;
 #pragma unroll
-        for (int f = 0; f < 8; ++f) A[nxt][f] = *reinterpret_cast<const V*>(smem + a_off + f * 1024);
+        for (int f = 0; f < 8; ++f) {
+            if ((KAMI_TOWER8_ABL & 4) && f > 0) A[nxt][f] = A[nxt][0];
+            else A[nxt][f] = *reinterpret_cast<const V*>(smem + a_off + f * 1024);
+        }
         if (n + 1 < S::NCH) {
 #pragma unroll
             for (int k = 0; k < KPC; ++k) {
                 if ((n + 1) * KPC + k < NREG) B[nxt][k] = breg[(n + 1) * KPC + k];
+                else if ((KAMI_TOWER8_ABL & 2) && k > 0) B[nxt][k] = B[nxt][0];
                 else B[nxt][k] = *reinterpret_cast<const V*>(smem + b_base + b_off8<TAPS, KS, BM>((n + 1) * KPC + k, stride));
             }
         }
@@ -371,6 +405,49 @@ __device__ __forceinline__ void zero_halo(char* base, int board_bytes, int t)
     }
 }
 
+// The value head's second half on the four helper waves: valuefc + tanh -> [B][256] (nn.cpp:86-88), thread j = output j.
+// The row is requested behind [BL], waits in registers while the compute waves reduce their logits ([BS1], [BS2]) and
+// is used while they scale and store the policy rows: off the workgroup's tail.  v64: the value conv's [TW_NB][64] in LDS.
+template <bool LEGAL>
+__device__ __forceinline__ void helper_value_fc(const TowerArgs& a, const float* v64, int b0, int j, int lane)
+{
+    asm volatile("s_barrier" ::: "memory");                                                 // [BL]
+    unsigned voff = (unsigned)j * 16u;        // (opaque: the optimiser would hoist 16 address pairs out of the group loop and spill them)
+    asm volatile("" : "+v"(voff));
+    float4 fcw[16];
+#pragma unroll
+    for (int k = 0; k < 16; ++k)
+        fcw[k] = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(a.fcw4) + (size_t)k * KH_VALUE_WIDTH * 16 + voff);
+    const float fcbias = a.fcb[j];
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_barrier" ::: "memory");                                                 // [BS1]
+    asm volatile("s_barrier" ::: "memory");                                                 // [BS2]
+    float s[TW_NB];
+#pragma unroll
+    for (int bb = 0; bb < TW_NB; ++bb) s[bb] = 0.0f;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+        const float4 w = fcw[k];
+#pragma unroll
+        for (int bb = 0; bb < TW_NB; ++bb) {
+            const float4 x = *reinterpret_cast<const float4*>(v64 + bb * 64 + k * 4);
+            s[bb] = fmaf(x.x, w.x, s[bb]); s[bb] = fmaf(x.y, w.y, s[bb]);
+            s[bb] = fmaf(x.z, w.z, s[bb]); s[bb] = fmaf(x.w, w.w, s[bb]);
+        }
+    }
+    bool nan = false;
+#pragma unroll
+    for (int bb = 0; bb < TW_NB; ++bb) {
+        if (b0 + bb < a.B) {
+            const float r = tanhf(s[bb] + fcbias);
+            nan |= (r != r);
+            a.vfull[(size_t)(b0 + bb) * KH_VALUE_WIDTH + j] = r;
+            if (LEGAL && j == 0) a.lg_values[b0 + bb] = r;               // column 0: the position's value
+        }
+    }
+    if (__any(nan) && lane == 0) raise_flag<LEGAL>(a, 1);
+}
+
 // ---------------------------------------------------------------- the kernel
 // KS_STEM = padded input planes / 16 (2 for F <= 32, 8 for F <= 128); LEGAL: legal-move mode (TowerArgs::lg_*).
 template <typename T, int KS_STEM, bool LEGAL = false>
@@ -412,90 +489,116 @@ __global__ __launch_bounds__(512) void tower8_kernel(TowerArgs a)
 #endif
     const int ngroups = (a.B + TW_NB - 1) / TW_NB;
 
-    if (wave >= 4) {
-        // =====================================================================================  helper waves
-        Pipe pipe;
-        pipe.stream = a.wstream; pipe.nch = a.nchunks; pipe.next = 0; pipe.islot = 0; pipe.cslot = 0; pipe.ring = LDS_RING;
-        bool first = true;
-        float4 fcw[16];                                     // valuefc row of output j = ct: fetched once, during the first tower
-        float fcbias = 0.0f;
-#pragma unroll
-        for (int k = 0; k < 16; ++k) fcw[k] = make_float4(0.f, 0.f, 0.f, 0.f);
-
+    if (wave >= 6) {
+        // =====================================================================================  plane waves (2)
+        // The input planes -> T in the S image, the T image's zero halo, the value head's FC.  These two waves issue no
+        // LDS-DMA, so the compiler's own counted waits on their loads are exact: a quarter is converted as soon as
+        // ITS loads have landed, whatever is still in flight behind them.
+        const int pt = tid & 127;
         for (int grp = blockIdx.x; grp < ngroups; grp += gridDim.x) {
             const int b0 = grp * TW_NB;
             if (KS_STEM == 8) {
-                // ---- planes, 33..128 of them: the stem runs as two 64-channel passes; both halves are requested up
-                //      front (the first group's ring prologue between them), the first is converted before [B0], the
-                //      second lands under the first pass and is converted between steps 3 and 4.  Item j of a thread
-                //      = (board, pixel) ct/8 + 32 j, channels 64 hh + 4 (ct%8) .. +3 and +32; loads are clamped into
-                //      the row / batch and masked afterwards so that every wave issues exactly 8 per half.
-                float4_u pl[2][4][2];
+                // ---- 33..128 planes, four quarters of 32: the stem walks the quarters in this order (BM_QUARTERS) and
+                //      starts when the FIRST has been converted; quarter q is converted, two items at a time between the
+                //      stem's barriers, before the barrier that precedes the first read of its chunks.  Item j of a thread =
+                //      (board, pixel) (pt + 128 j) / 8, channels 32 q + 4 (pt % 8) .. +3: a wave load covers 8 pixels x
+                //      128 contiguous bytes.  Loads are clamped into the row / batch and masked afterwards.
+                float4_u pl[4][8];
+                const int lc = pt & 7;
+                const int nb = min(TW_NB, a.B - b0);                 // live boards of this group; a dead one re-reads the last live one
+                const char* gbase = reinterpret_cast<const char*>(a.in + (size_t)b0 * 64 * F);     // wave-uniform
+                unsigned voff[8];                                    // byte offset of item j's pixel row from gbase
 #pragma unroll
-                for (int hh = 0; hh < 2; ++hh) {
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        const int bp = (ct >> 3) + 32 * j;
-                        const int brd = min(b0 + (bp >> 6), a.B - 1);
-                        const float* row = a.in + ((size_t)brd * 64 + (bp & 63)) * F;
-                        const int c = hh * 64 + 4 * (ct & 7);
-                        pl[hh][j][0] = __builtin_nontemporal_load(reinterpret_cast<const float4_u*>(row + min(c, F - 4)));
-                        pl[hh][j][1] = __builtin_nontemporal_load(reinterpret_cast<const float4_u*>(row + min(c + 32, F - 4)));
-                    }
-                    __builtin_amdgcn_sched_barrier(0);
-                    if (hh == 0 && first) {
-#pragma unroll
-                        for (int i = 0; i < RING_D - 1; ++i) pipe_issue(pipe, cw, lane);
-                    }
+                for (int j = 0; j < 8; ++j) {
+                    const int ip = (pt >> 3) + 16 * j;
+                    voff[j] = (unsigned)((min(ip >> 6, nb - 1) * 64 + (ip & 63)) * F) * 4u;
                 }
-                // the first half and everything older (ring chunks 0..4 of the first group) have landed
-                asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-                ingest_half<T>(pl[0], 0, smem + LDS_ST, SSTR, SBOARD, b0, ct, lane, a);
+                // S offset of item 0's pixel, + this lane's 8 bytes; item j adds (j >> 2) boards and 2 (j & 3) pixel rows
+                const unsigned sdst = LDS_ST + ((((pt >> 6) + 1) * PITCH + ((pt >> 3) & 7) + 1) * SSTR) + 8 * lc;
+                float badacc = 0.0f;                                 // x * 0 summed over every plane value: NaN iff one is NaN or Inf
+                auto request = [&](int q) {
+                    // read-once stream: non-temporal, so that the XCD's L2 keeps the weight stream
+                    const unsigned cc = (unsigned)min(32 * q + 4 * lc, F - 4) * 4u;
+#pragma unroll
+                    for (int j = 0; j < 8; ++j)
+                        pl[q][j] = __builtin_nontemporal_load(reinterpret_cast<const float4_u*>(gbase + voff[j] + cc));
+                };
+                auto convert = [&](int q, int j) {
+                    float x[4] = { pl[q][j].x, pl[q][j].y, pl[q][j].z, pl[q][j].w };
+                    if (32 * q + 32 > F) {                           // (wave-uniform) a quarter that holds the row's ragged end
+                        const int c = 32 * q + 4 * lc;
+                        const int sh = c - min(c, F - 4);            // the load was moved back by sh channels; channels >= F are zero
+                        float y[4];
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) {
+                            y[k] = sh == 0 ? x[k] : 0.0f;
+#pragma unroll
+                            for (int m = 1; m < 4; ++m)
+                                if (k + m < 4) y[k] = sh == m ? x[k + m] : y[k];
+                        }
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) x[k] = y[k];
+                    }
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) badacc = fmaf(x[k], 0.0f, badacc);
+                    u32x2 o;
+                    o.x = pack2<T>(x[0], x[1]); o.y = pack2<T>(x[2], x[3]);
+                    *reinterpret_cast<u32x2*>(smem + sdst + (j >> 2) * SBOARD + (j & 3) * 2 * PITCH * SSTR + 64 * q) = o;
+                };
+                request(0); request(1);
+                T8_STAMP(6);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) convert(0, j);
+                request(2);                  // (two quarters in flight is what the CU's memory pipeline takes without stalling the issue)
+                T8_STAMP(8);
                 lds_barrier();                                                              // [B0]
-                first = false;
                 T8_STAMP(2);
-                // pass 1's first T8_RELAX steps wait for chunks requested before the second half's loads
+                // quarter q's first chunk is chunk (18 q + 3) / 4 = 0, 4, 9, 13: read behind that step's barrier
+                //   slot (between barriers)   s0 s1 s2 s3 | s4 s5 s6 s7 s8 | s9 s10 s11 s12 | ...
+                //   items converted           q1: 2 2 2 2 | q2: 2 2 2 1 1  | q3: 2  2   2   2
 #pragma unroll
-                for (int i = 0; i < T8_RELAX; ++i) hpipe_step<8>(pipe, cw, lane);
-                ingest_half<T>(pl[1], 1, smem + LDS_ST, SSTR, SBOARD, b0, ct, lane, a);
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                for (int i = T8_RELAX; i < NSTEM; ++i) hpipe_step<0>(pipe, cw, lane);
-            } else {
-                if (first) {
-#pragma unroll
-                    for (int i = 0; i < RING_D - 1; ++i) pipe_issue(pipe, cw, lane);
+                for (int i = 0; i < NSTEM; ++i) {
+                    if (i < 4) { convert(1, 2 * i); convert(1, 2 * i + 1); }
+                    else if (i < 7) { convert(2, 2 * (i - 4)); convert(2, 2 * (i - 4) + 1); }
+                    else if (i < 9) convert(2, i - 1);
+                    else if (i < 13) { convert(3, 2 * (i - 9)); convert(3, 2 * (i - 9) + 1); }
+                    if (i == 0) request(3);
+                    if (i == 3 || i == 8 || i == 12) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // a quarter complete
+                    asm volatile("s_barrier" ::: "memory");                                 // [stem step i]
                 }
+                const bool bad = badacc != badacc;
+                // a NaN/Inf plane value makes the reference's policy NaN (nn.cpp:176): same verdict here
+                if (__any(bad) && lane == 0) raise_flag<LEGAL>(a, 0);
+            } else {
                 if (a.boards) {
                     // ---- compact ingest: Env::observe (env.h:202-262) straight into S, one thread per (board, square)
-                    if (ct < TW_NB * 64) {
-                        const int bb = ct >> 6, p = ct & 63;
-                        float v[32];
+                    const int bb = pt >> 6, p = pt & 63;
+                    float v[32];
 #pragma unroll
-                        for (int k = 0; k < 32; ++k) v[k] = 0.0f;
-                        if (b0 + bb < a.B) {
-                            float w[KH_NFEATURES];
-                            encode_square(a.boards + (b0 + bb), p, w);
+                    for (int k = 0; k < 32; ++k) v[k] = 0.0f;
+                    if (b0 + bb < a.B) {
+                        float w[KH_NFEATURES];
+                        encode_square(a.boards + (b0 + bb), p, w);
 #pragma unroll
-                            for (int k = 0; k < KH_NFEATURES; ++k) v[k] = w[k];
-                        }
-                        char* dst = smem + LDS_ST + bb * SBOARD + (((p >> 3) + 1) * PITCH + (p & 7) + 1) * SSTR;
+                        for (int k = 0; k < KH_NFEATURES; ++k) v[k] = w[k];
+                    }
+                    char* dst = smem + LDS_ST + bb * SBOARD + (((p >> 3) + 1) * PITCH + (p & 7) + 1) * SSTR;
 #pragma unroll
-                        for (int c = 0; c < 4; ++c) {
-                            u32x4 o;
-                            o.x = pack2<T>(v[8 * c + 0], v[8 * c + 1]); o.y = pack2<T>(v[8 * c + 2], v[8 * c + 3]);
-                            o.z = pack2<T>(v[8 * c + 4], v[8 * c + 5]); o.w = pack2<T>(v[8 * c + 6], v[8 * c + 7]);
-                            *reinterpret_cast<u32x4*>(dst + c * 16) = o;
-                        }
+                    for (int c = 0; c < 4; ++c) {
+                        u32x4 o;
+                        o.x = pack2<T>(v[8 * c + 0], v[8 * c + 1]); o.y = pack2<T>(v[8 * c + 2], v[8 * c + 3]);
+                        o.z = pack2<T>(v[8 * c + 4], v[8 * c + 5]); o.w = pack2<T>(v[8 * c + 6], v[8 * c + 7]);
+                        *reinterpret_cast<u32x4*>(dst + c * 16) = o;
                     }
                 } else {
                     // ---- planes fp32 [b][64][F], F <= 32 -> T in S (interior pixels, all FP channels)
                     constexpr int CH = FP / 8;                       // 8-channel (16-byte) chunks per pixel of S
-                    constexpr int NIT = TW_NB * 64 * CH / 256;       // (board, pixel, chunk) items per thread
+                    constexpr int NIT = TW_NB * 64 * CH / 128;       // (board, pixel, chunk) items per thread
                     float vin[NIT][8];
-                    const int c0 = (ct % CH) * 8;
+                    const int c0 = (pt % CH) * 8;
 #pragma unroll
                     for (int j = 0; j < NIT; ++j) {
-                        const int i = ct + 256 * j;
+                        const int i = pt + 128 * j;
                         const int bb = i / (64 * CH), p = (i / CH) & 63;
                         const float* src = a.in + ((size_t)(b0 + bb) * 64 + p) * F + c0;
                         const bool live = (b0 + bb) < a.B;
@@ -512,84 +615,63 @@ __global__ __launch_bounds__(512) void tower8_kernel(TowerArgs a)
                     bool bad = false;
 #pragma unroll
                     for (int j = 0; j < NIT; ++j) {
-                        const int i = ct + 256 * j;
+                        const int i = pt + 128 * j;
                         const int bb = i / (64 * CH), p = (i / CH) & 63;
                         u32x4 o;
                         unsigned w[4];
 #pragma unroll
                         for (int k = 0; k < 4; ++k) {
                             const float lo = vin[j][2 * k], hi = vin[j][2 * k + 1];
-                            bad = bad || ((__float_as_uint(lo) & 0x7f800000u) == 0x7f800000u) || ((__float_as_uint(hi) & 0x7f800000u) == 0x7f800000u);
+                            bad = bad || !__builtin_isfinite(lo) || !__builtin_isfinite(hi);
                             w[k] = pack2<T>(lo, hi);
                         }
                         o.x = w[0]; o.y = w[1]; o.z = w[2]; o.w = w[3];
-                        *reinterpret_cast<u32x4*>(smem + LDS_ST + bb * SBOARD + (((p >> 3) + 1) * PITCH + (p & 7) + 1) * SSTR + (ct % CH) * 16) = o;
+                        *reinterpret_cast<u32x4*>(smem + LDS_ST + bb * SBOARD + (((p >> 3) + 1) * PITCH + (p & 7) + 1) * SSTR + (pt % CH) * 16) = o;
                     }
-                    // a NaN/Inf plane value makes the reference's policy NaN (nn.cpp:176): same verdict here
                     if (__any(bad) && lane == 0) raise_flag<LEGAL>(a, 0);
                 }
-                // everything requested so far has landed: the planes and, in the first group, ring chunks 0..4
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 lds_barrier();                                                              // [B0]
-                first = false;
                 T8_STAMP(2);
-                for (int i = 0; i < NSTEM; ++i) hpipe_step<0>(pipe, cw, lane);
+                for (int i = 0; i < NSTEM; ++i) asm volatile("s_barrier" ::: "memory");     // [stem steps]
             }
             T8_STAMP(5);
-            // tower + policy steps.  In the first group the valuefc row is requested here: 17 loads younger than
-            // the ring's, which the next T8_RELAX steps' waits leave in flight.
-            int relax = 0;
-            if (grp == (int)blockIdx.x) {
-#pragma unroll
-                for (int k = 0; k < 16; ++k)
-                    fcw[k] = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(a.fcw4) + (size_t)k * KH_VALUE_WIDTH * 16 + (unsigned)ct * 16u);
-                fcbias = a.fcb[ct];
-                __builtin_amdgcn_sched_barrier(0);
-                relax = T8_RELAX;
-            }
             const int nsteps = 2 * R * NLAYER + NPOL;
             for (int i = 0; i < nsteps; ++i) {
-                if (relax > 0) { hpipe_step<17>(pipe, cw, lane); --relax; }
-                else hpipe_step<0>(pipe, cw, lane);
+                asm volatile("s_barrier" ::: "memory");                                     // [tower + policy steps]
                 if (i == 0 && R > 0) {
                     // behind the first tower step's barrier every compute wave's last read of S is complete: T, which
                     // shares LDS with S, gets its zero halo, nine steps before conv2 of the first block reads through it
-                    zero_halo<XSTR>(smem + LDS_ST, XBOARD, ct);
+                    for (int z = 0; z < 2; ++z) zero_halo<XSTR>(smem + LDS_ST, XBOARD, pt + 128 * z);
                     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 }
             }
             T8_STAMP(19);
-            asm volatile("s_barrier" ::: "memory");                                         // [BL] logits in LDS; v64 since 4a
-            // ---- value head, second half: valuefc + tanh -> [B][256] (nn.cpp:86-88), under the compute waves' softmax
-            {
-                float s[TW_NB];
-#pragma unroll
-                for (int bb = 0; bb < TW_NB; ++bb) s[bb] = 0.0f;
-#pragma unroll
-                for (int k = 0; k < 16; ++k) {
-                    const float4 w = fcw[k];
-#pragma unroll
-                    for (int bb = 0; bb < TW_NB; ++bb) {
-                        const float4 x = *reinterpret_cast<const float4*>(v64 + bb * 64 + k * 4);
-                        s[bb] = fmaf(x.x, w.x, s[bb]); s[bb] = fmaf(x.y, w.y, s[bb]);
-                        s[bb] = fmaf(x.z, w.z, s[bb]); s[bb] = fmaf(x.w, w.w, s[bb]);
-                    }
-                }
-                bool nan = false;
-#pragma unroll
-                for (int bb = 0; bb < TW_NB; ++bb) {
-                    if (b0 + bb < a.B) {
-                        const float r = tanhf(s[bb] + fcbias);
-                        nan |= (r != r);
-                        a.vfull[(size_t)(b0 + bb) * KH_VALUE_WIDTH + ct] = r;
-                        if (LEGAL && ct == 0) a.lg_values[b0 + bb] = r;               // column 0: the position's value
-                    }
-                }
-                if (__any(nan) && lane == 0) raise_flag<LEGAL>(a, 1);
-            }
+            helper_value_fc<LEGAL>(a, v64, b0, tid & 255, lane);                            // [BL] [BS1] [BS2] inside
             T8_STAMP(21);
-            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");                 // [BS1]
-            asm volatile("s_barrier" ::: "memory");                                         // [BS2]
+            asm volatile("s_barrier" ::: "memory");                                         // [BE]
+            T8_STAMP(22);
+        }
+    } else if (wave >= 4) {
+        // =====================================================================================  stream waves (2)
+        // The weight stream's LDS-DMA (four 1 KB pieces of every chunk each); behind a group's last step also its half of
+        // the value FC.  The counted waits of the steps see exactly the ring's operations.
+        const int hw = wave - 4;
+        Pipe pipe;
+        pipe.stream = a.wstream; pipe.nch = a.nchunks; pipe.next = 0; pipe.islot = 0; pipe.cslot = 0; pipe.ring = LDS_RING;
+#pragma unroll
+        for (int i = 0; i < RING_D - 1; ++i) pipe_issue4(pipe, hw, lane);
+        const int nsteps = NSTEM + 2 * R * NLAYER + NPOL;
+
+        for (int grp = blockIdx.x; grp < ngroups; grp += gridDim.x) {
+            // chunks 0 and 1 of this group have landed (chunks 2, 3, 4 may still be in flight)
+            asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(4 * (RING_D - 3)) : "memory");                 // [B0]
+            T8_STAMP(2);
+            for (int i = 0; i < nsteps; ++i) hpipe_step<0>(pipe, hw, lane);
+            T8_STAMP(19);
+            // (the stream is at rest until the next group's first step: these loads and stores are the youngest
+            //  operations, every ring piece older than them has long landed)
+            helper_value_fc<LEGAL>(a, v64, grp * TW_NB, tid & 255, lane);                   // [BL] [BS1] [BS2] inside
+            T8_STAMP(21);
             asm volatile("s_barrier" ::: "memory");                                         // [BE]
             T8_STAMP(22);
         }
@@ -613,8 +695,21 @@ __global__ __launch_bounds__(512) void tower8_kernel(TowerArgs a)
 
         CPipe pipe;
         pipe.ring = LDS_RING; pipe.cslot = 0;
-        // parameter block -> LDS
-        for (int i = ct; i < a.npar; i += 256) par[i] = a.params[i];
+        // parameter block -> LDS: all of a thread's float4 requested before the first is stored (npar is a multiple of 4;
+        // a dependent load -> store round trip per iteration cost 5 000 cycles behind the plane waves' traffic)
+        {
+            const float4* src = reinterpret_cast<const float4*>(a.params);
+            float4* dst = reinterpret_cast<float4*>(par);
+            const int n4 = a.npar >> 2;
+            for (int i0 = 0; i0 < n4; i0 += 4 * 256) {
+                const float4 v0 = src[min(i0 + ct, n4 - 1)], v1 = src[min(i0 + 256 + ct, n4 - 1)];
+                const float4 v2 = src[min(i0 + 512 + ct, n4 - 1)], v3 = src[min(i0 + 768 + ct, n4 - 1)];
+                if (i0 + ct < n4) dst[i0 + ct] = v0;
+                if (i0 + 256 + ct < n4) dst[i0 + 256 + ct] = v1;
+                if (i0 + 512 + ct < n4) dst[i0 + 512 + ct] = v2;
+                if (i0 + 768 + ct < n4) dst[i0 + 768 + ct] = v3;
+            }
+        }
         T8_STAMP(1);
 
         V A[2][8];                             // two register sets of weight fragments (current / next chunk)
@@ -645,8 +740,8 @@ __global__ __launch_bounds__(512) void tower8_kernel(TowerArgs a)
             V B[2][4];
             acc_init<2>(accA, shift3, h);
             {
-                // 33..128 planes: two passes of 64 channels (planes 0..63, then 64..127), one 18-chunk walk
-                constexpr int BMS = KS_STEM == 8 ? BM_HALVES : BM_RASTER;
+                // 33..128 planes: four passes of 32 channels in one 18-chunk walk
+                constexpr int BMS = KS_STEM == 8 ? BM_QUARTERS : BM_RASTER;
 #pragma unroll
                 for (int k = 0; k < 4; ++k) B[0][k] = *reinterpret_cast<const V*>(smem + sin + b_off8<9, KS_STEM, BMS>(k, SSTR));
                 gemm8_steps<T, 9, KS_STEM, 2, 0, 0, BMS, 0, NSTEM - 1>(pipe, smem, lane, sin, SSTR, accA, A, B);

@@ -671,10 +671,15 @@ int tower_lds_bytes(int FP, int R)
 #define KAMI_TOWER_DEFAULT_V 4
 #endif
 
+int tower_variant()
+{
+    static const int variant = [] { const char* v = getenv("KAMI_TOWER_V"); return v && *v && atoi(v) == 4 ? 4 : (v && *v && atoi(v) == 8 ? 8 : KAMI_TOWER_DEFAULT_V); }();
+    return variant;
+}
+
 hipError_t launch_tower(int dtype, int FP, const TowerArgs& a, int num_cus, hipStream_t s)
 {
-    static const int variant = [] { const char* v = getenv("KAMI_TOWER_V"); return v && *v ? atoi(v) : KAMI_TOWER_DEFAULT_V; }();
-    if (variant == 8) return launch_tower8(dtype, FP, a, num_cus, s);
+    if (tower_variant() == 8) return launch_tower8(dtype, FP, a, num_cus, s);
     const int ngroups = (a.B + TW_NB - 1) / TW_NB;
     const int grid = ngroups < num_cus ? ngroups : num_cus;      // one workgroup per CU (LDS-bound residency)
     if (a.lg_offsets) {                      // legal-move mode: compact records (F <= 32) only

@@ -34,9 +34,12 @@ st = rows[0::2][:nwg].reshape(nwg, 4, 32).astype(np.int64)      # [wg][wave][sta
 if a.v8:
     hs = rows[1::2][:nwg].reshape(nwg, 4, 32).astype(np.int64)
     t0 = st[:, :, 0].min(axis=1)[:, None]
-    print("helper waves, cycles since the workgroup's first compute-wave stamp (median over workgroups and waves):")
-    for k, nm in ((0, "entry"), (2, "planes half 0 converted, [B0]"), (5, "stem steps done, [B1]"), (19, "all steps done"), (21, "value fc done"), (22, "group done"), (23, "drained")):
-        print(f"   {nm:34s} {np.median(hs[:, :, k] - t0):8.0f}")
+    print("cycles since the workgroup's first compute-wave stamp (median over workgroups and the role's two waves):")
+    for role, w0, items in (("plane waves", 2, ((0, "entry"), (10, "quarter 0 loads issued"), (11, "quarter 1 loads issued"), (12, "quarter 2 loads issued"), (13, "quarter 3 loads issued"), (6, "plane loads issued"), (14, "quarter 0 landed (STAMP=2 builds)"), (15, "quarter 1 landed"), (16, "quarter 2 landed"), (17, "quarter 3 landed"), (8, "quarter 0 converted"), (2, "[B0] passed"), (5, "stem steps done"), (19, "all steps done"), (22, "group done"))),
+                            ("stream waves", 0, ((0, "entry"), (2, "[B0] passed"), (19, "all steps done"), (21, "value fc done"), (22, "group done"), (23, "drained")))):
+        print(f" {role}:")
+        for k, nm in items:
+            print(f"   {nm:34s} {np.median(hs[:, w0:w0 + 2, k] - t0):8.0f}")
     print("compute waves:")
 t = st[:, :, :24]
 rt = st[:, :, 31] - st[:, :, 30]
