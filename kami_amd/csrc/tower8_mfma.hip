@@ -46,6 +46,9 @@ namespace kh {
 // compute wave finished reading two steps ago — with chunk c + RING_D - 1: requested RING_D - 3 steps before its
 // barrier.  Barrier c may sit anywhere between the reads of chunk c (step c - 1) and those of chunk c + 2 (step c + 1).
 constexpr int T8_LAG = 1;
+// (Tried and dropped: the stream waves bringing the weights global -> registers -> ds_write_b128 instead of LDS-DMA — six
+//  chunks deep in registers, compiler-counted waits: bit-identical, 35.4 us against the LDS-DMA's 32.5 on the same device,
+//  profiles/r03_tower8_wreg_ab.txt.  Two waves' wide LDS stores run at half the store path's rate.)
 struct CPipe { unsigned ring; int cslot; };
 
 __device__ __forceinline__ unsigned cpipe_advance(CPipe& p)      // next chunk's LDS offset, no barrier
@@ -425,12 +428,17 @@ __device__ __forceinline__ void helper_value_fc(const TowerArgs& a, const float*
     float s[TW_NB];
 #pragma unroll
     for (int bb = 0; bb < TW_NB; ++bb) s[bb] = 0.0f;
+    static_assert(TW_NB == 2, "value FC: two boards per workgroup");
 #pragma unroll
     for (int k = 0; k < 16; ++k) {
+        // four k-groups at a time: the reads' base is re-defined behind the previous four groups' sums, so that the 32
+        // broadcast reads of v64 are not all hoisted to the top (128 registers, and spills beside the stream's buffers)
+        const float* vb = v64 + (k & ~3) * 4;
+        if ((k & 3) == 0) asm volatile("" : "+v"(vb), "+v"(s[0]), "+v"(s[1]));
         const float4 w = fcw[k];
 #pragma unroll
         for (int bb = 0; bb < TW_NB; ++bb) {
-            const float4 x = *reinterpret_cast<const float4*>(v64 + bb * 64 + k * 4);
+            const float4 x = *reinterpret_cast<const float4*>(vb + bb * 64 + (k & 3) * 4);
             s[bb] = fmaf(x.x, w.x, s[bb]); s[bb] = fmaf(x.y, w.y, s[bb]);
             s[bb] = fmaf(x.z, w.z, s[bb]); s[bb] = fmaf(x.w, w.w, s[bb]);
         }
@@ -653,14 +661,13 @@ __global__ __launch_bounds__(512) void tower8_kernel(TowerArgs a)
         }
     } else if (wave >= 4) {
         // =====================================================================================  stream waves (2)
-        // The weight stream's LDS-DMA (four 1 KB pieces of every chunk each); behind a group's last step also its half of
-        // the value FC.  The counted waits of the steps see exactly the ring's operations.
+        // The weight stream (each wave one half of every 8 KB chunk); behind a group's last step also its half of the value FC.
         const int hw = wave - 4;
+        const int nsteps = NSTEM + 2 * R * NLAYER + NPOL;
         Pipe pipe;
         pipe.stream = a.wstream; pipe.nch = a.nchunks; pipe.next = 0; pipe.islot = 0; pipe.cslot = 0; pipe.ring = LDS_RING;
 #pragma unroll
         for (int i = 0; i < RING_D - 1; ++i) pipe_issue4(pipe, hw, lane);
-        const int nsteps = NSTEM + 2 * R * NLAYER + NPOL;
 
         for (int grp = blockIdx.x; grp < ngroups; grp += gridDim.x) {
             // chunks 0 and 1 of this group have landed (chunks 2, 3, 4 may still be in flight)
