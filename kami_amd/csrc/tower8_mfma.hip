@@ -523,7 +523,7 @@ __global__ __launch_bounds__(512) void tower8_kernel(TowerArgs a)
                 }
                 // S offset of item 0's pixel, + this lane's 8 bytes; item j adds (j >> 2) boards and 2 (j & 3) pixel rows
                 const unsigned sdst = LDS_ST + ((((pt >> 6) + 1) * PITCH + ((pt >> 3) & 7) + 1) * SSTR) + 8 * lc;
-                float badacc = 0.0f;                                 // x * 0 summed over every plane value: NaN iff one is NaN or Inf
+                unsigned badmax = 0u;                                // max over every plane value's bits without the sign: >= 0x7f800000 iff one is NaN or Inf
                 auto request = [&](int q) {
                     // read-once stream: non-temporal, so that the XCD's L2 keeps the weight stream
                     const unsigned cc = (unsigned)min(32 * q + 4 * lc, F - 4) * 4u;
@@ -547,17 +547,21 @@ __global__ __launch_bounds__(512) void tower8_kernel(TowerArgs a)
 #pragma unroll
                         for (int k = 0; k < 4; ++k) x[k] = y[k];
                     }
-#pragma unroll
-                    for (int k = 0; k < 4; ++k) badacc = fmaf(x[k], 0.0f, badacc);
+                    // (integer max on the bits: an x * 0 sum is folded away by the optimiser, four v_cmp_class + s_or per item
+                    //  made the plane waves late at the stem's barriers — +2 000 cycles on the stem)
+                    badmax = max(max(badmax, __float_as_uint(x[0]) & 0x7fffffffu), __float_as_uint(x[1]) & 0x7fffffffu);
+                    badmax = max(max(badmax, __float_as_uint(x[2]) & 0x7fffffffu), __float_as_uint(x[3]) & 0x7fffffffu);
                     u32x2 o;
                     o.x = pack2<T>(x[0], x[1]); o.y = pack2<T>(x[2], x[3]);
                     *reinterpret_cast<u32x2*>(smem + sdst + (j >> 2) * SBOARD + (j & 3) * 2 * PITCH * SSTR + 64 * q) = o;
                 };
-                request(0); request(1);
+                // everything requested up front: the issue stalls at the memory pipeline's depth (two quarters), but all four
+                // quarters have landed ~900 cycles after the last request and the pipeline is then free for the stem's
+                // weights (two quarters in flight and the others requested between the steps: 0.4 % slower, same device)
+                request(0); request(1); request(2); request(3);
                 T8_STAMP(6);
 #pragma unroll
                 for (int j = 0; j < 8; ++j) convert(0, j);
-                request(2);                  // (two quarters in flight is what the CU's memory pipeline takes without stalling the issue)
                 T8_STAMP(8);
                 lds_barrier();                                                              // [B0]
                 T8_STAMP(2);
@@ -570,11 +574,10 @@ __global__ __launch_bounds__(512) void tower8_kernel(TowerArgs a)
                     else if (i < 7) { convert(2, 2 * (i - 4)); convert(2, 2 * (i - 4) + 1); }
                     else if (i < 9) convert(2, i - 1);
                     else if (i < 13) { convert(3, 2 * (i - 9)); convert(3, 2 * (i - 9) + 1); }
-                    if (i == 0) request(3);
                     if (i == 3 || i == 8 || i == 12) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // a quarter complete
                     asm volatile("s_barrier" ::: "memory");                                 // [stem step i]
                 }
-                const bool bad = badacc != badacc;
+                const bool bad = badmax >= 0x7f800000u;
                 // a NaN/Inf plane value makes the reference's policy NaN (nn.cpp:176): same verdict here
                 if (__any(bad) && lane == 0) raise_flag<LEGAL>(a, 0);
             } else {
