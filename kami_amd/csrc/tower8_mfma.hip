@@ -37,6 +37,14 @@
 
 namespace kh {
 
+// Output stores are WRITE-THROUGH (sc1): the policy rows are 9.6 MB per batch-512 launch, written in the kernel's last
+// phase; with plain or non-temporal stores they sit dirty in the XCDs' L2s when the kernel ends and the end-of-kernel
+// release writes them back before the next launch may start — 1.7 us of every 32 (same-device A/B of the store's cache
+// policy: nt 31.92, plain 31.96, sc1 30.22, sc0 sc1 30.21, sc1 nt 30.32 us; profiles/r03_tower8_store_policy_ab.txt).
+using f32x4_t = float __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void store_wt(f32x4_t* p, f32x4_t v) { asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(p), "v"(v) : "memory"); }
+__device__ __forceinline__ void store_wt(float* p, float v) { asm volatile("global_store_dword %0, %1, off sc1" ::"v"(p), "v"(v) : "memory"); }
+
 // ---------------------------------------------------------------- ring protocol, two roles
 // Chunk c lives in slot c mod RING_D.  Step c of a compute wave multiplies chunk c (in registers since step c - 1)
 // and reads chunk c + 1 into its other register set.  Before barrier c a helper wave has waited for its two pieces of
@@ -425,6 +433,7 @@ __device__ __forceinline__ void helper_value_fc(const TowerArgs& a, const float*
     __builtin_amdgcn_sched_barrier(0);
     asm volatile("s_barrier" ::: "memory");                                                 // [BS1]
     asm volatile("s_barrier" ::: "memory");                                                 // [BS2]
+    // (the sums between [BS1] and [BS2] instead of behind [BS2]: no difference, 30.58 / 30.62 us on one device)
     float s[TW_NB];
 #pragma unroll
     for (int bb = 0; bb < TW_NB; ++bb) s[bb] = 0.0f;
@@ -449,7 +458,7 @@ __device__ __forceinline__ void helper_value_fc(const TowerArgs& a, const float*
         if (b0 + bb < a.B) {
             const float r = tanhf(s[bb] + fcbias);
             nan |= (r != r);
-            a.vfull[(size_t)(b0 + bb) * KH_VALUE_WIDTH + j] = r;
+            store_wt(a.vfull + (size_t)(b0 + bb) * KH_VALUE_WIDTH + j, r);
             if (LEGAL && j == 0) a.lg_values[b0 + bb] = r;               // column 0: the position's value
         }
     }
@@ -899,7 +908,7 @@ __global__ __launch_bounds__(512) void tower8_kernel(TowerArgs a)
                         if (tt + 128 * k < NQ) {
                             using f4 = float __attribute__((ext_vector_type(4)));
                             const f4 ov = { o.x, o.y, o.z, o.w };
-                            __builtin_nontemporal_store(ov, reinterpret_cast<f4*>(po) + tt + 128 * k);
+                            store_wt(reinterpret_cast<f4*>(po) + tt + 128 * k, ov);
                         }
                     }
                 }

@@ -21,7 +21,10 @@ constexpr int XBOARD = NPIX * XSTR;             // 17 280
 constexpr int PSTR = KH_POLICY_MID * 2 + 16;    // 272: pixel stride of the policy mid image
 constexpr int PBOARD = 64 * PSTR;               // dense 64 pixels (1x1 conv needs no halo)
 constexpr int LBOARD = KH_PSIZE * 4;            // logits fp32 per board
-constexpr int RING_D = 6;
+#ifndef KAMI_RING_D
+#define KAMI_RING_D 6
+#endif
+constexpr int RING_D = KAMI_RING_D;      // (7 fits the LDS too: tried for one more step of prefetch lead, see DESIGN)
 constexpr int CHUNK = 8192;                     // 8 fragments of 1 KB
 // The DMA ring sits at LDS offset 0 so that its addresses fit M0's 16-bit LDS offset field.
 constexpr int LDS_RING = 0;

@@ -668,7 +668,7 @@ int tower_lds_bytes(int FP, int R)
 }
 
 #ifndef KAMI_TOWER_DEFAULT_V
-#define KAMI_TOWER_DEFAULT_V 4
+#define KAMI_TOWER_DEFAULT_V 8
 #endif
 
 int tower_variant()
