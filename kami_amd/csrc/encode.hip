@@ -16,6 +16,7 @@ namespace kh {
 constexpr int ENC_WAVES = 4;                 // waves per workgroup
 constexpr int ENC_TILE = 64 * KH_NFEATURES;  // floats per position
 
+template <bool WT>
 __global__ __launch_bounds__(64 * ENC_WAVES) void encode_f32_kernel(const kh_board* __restrict__ boards,
                                                                     int n, float* __restrict__ planes)
 {
@@ -43,7 +44,14 @@ __global__ __launch_bounds__(64 * ENC_WAVES) void encode_f32_kernel(const kh_boa
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
                 const int q = lane + 64 * j;
-                if (q < ENC_TILE / 4) __builtin_nontemporal_store(src[q], &out[q]);   // write-once stream
+                if (q < ENC_TILE / 4) {
+                    // write-once stream.  Up to the Infinity Cache's size write-through (sc1) stores win: nothing is left
+                    // dirty in L2 for the end-of-kernel release (8 192 positions: 9.7 us against 11.1 non-temporal, 10.8
+                    // plain); beyond it non-temporal stores do (2^20 positions: 5.89 TB/s against 5.77 / 5.67) —
+                    // profiles/r03_encode_store_ab.txt
+                    if (WT) asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(&out[q]), "v"(src[q]) : "memory");
+                    else __builtin_nontemporal_store(src[q], &out[q]);
+                }
             }
         }
         __syncthreads();
@@ -55,8 +63,10 @@ void launch_encode_f32(const kh_board* d_boards, int n, float* d_planes, hipStre
     if (n <= 0) return;
     int wgs = (n + ENC_WAVES - 1) / ENC_WAVES;
     if (wgs > 256 * 5) wgs = 256 * 5;        // 30 KB LDS per workgroup -> 5 resident per CU
-    hipLaunchKernelGGL(encode_f32_kernel, dim3(wgs), dim3(64 * ENC_WAVES),
-                       ENC_WAVES * ENC_TILE * sizeof(float), s, d_boards, n, d_planes);
+    if ((size_t)n * ENC_TILE * sizeof(float) <= ((size_t)128 << 20))
+        hipLaunchKernelGGL(encode_f32_kernel<true>, dim3(wgs), dim3(64 * ENC_WAVES), ENC_WAVES * ENC_TILE * sizeof(float), s, d_boards, n, d_planes);
+    else
+        hipLaunchKernelGGL(encode_f32_kernel<false>, dim3(wgs), dim3(64 * ENC_WAVES), ENC_WAVES * ENC_TILE * sizeof(float), s, d_boards, n, d_planes);
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -1234,7 +1234,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         // (same wave wrote it: its LDS operations are ordered)
         if (live) {
             for (int i = lane; i < KH_PSIZE / 4; i += 64)
-                __builtin_nontemporal_store(*reinterpret_cast<const f32x4s*>(rowbuf + 4 * i), reinterpret_cast<f32x4s*>(dst_row) + i);
+                // write-through (sc1): the rows are final outputs of the forward's last launch — nothing of them stays dirty
+                // in L2 for the end-of-kernel release to write back (tower8_mfma.hip: store_wt)
+                asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(reinterpret_cast<f32x4s*>(dst_row) + i), "v"(*reinterpret_cast<const f32x4s*>(rowbuf + 4 * i)) : "memory");
         }
     };
     if (a.logits) put_row(a.logits + (size_t)(live ? b : 0) * KH_PSIZE, false);
