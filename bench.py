@@ -18,7 +18,11 @@ The ONE JSON line carries, besides the contract's fields:
   end_to_end    (N = 1) what a caller of the host-buffer ABI sees, PCIe included: kh_infer (the legacy float ABI of
                 NN::infer) from 1 and 4 threads, kh_encode_infer_legal (compact records in, legal priors out)
   cpu_baseline  (N = 1) the unmodified reference's NN::infer on this box's host cores, bounded sample
-`value` is always the configs[1] kernel-path number; nothing in variants / end_to_end replaces it.
+  value_f32 / roofline_f32   (N = 1) the same step in the REFERENCE's arithmetic (exact fp32 on the matrix cores)
+  encode        (N = 1) the board -> plane encoder alone (Env::observe, env.h:202-262) against its HBM-write roofline
+  configs0      (N = 1) BASELINE configs[0]'s shape on the engine: one game, 64 sims per move, batch-1 evaluations
+`value` is always the configs[1] kernel-path number; nothing in variants / end_to_end replaces it.  The timed output is
+checked after the timed region: sampled rows must equal, bit for bit, kh_infer_full of the same input.
 """
 import argparse
 import ctypes as C
@@ -219,6 +223,52 @@ def variant_legs(torch, lib, NN, W, L, device, prewarm):
     return out
 
 
+def encode_leg(torch, lib, NN, L, device):
+    """Env::observe (env.h:202-262) alone: compact records in HBM -> fp32 planes in HBM, HBM-write bound (80 B read +
+    7 680 B written per position); at the headline batch and at 2^20 positions."""
+    import numpy as np
+    nn = NN(filters=8, residuals=0, device=device)
+    out = {"bound": "hbm", "peak": 8000.0, "unit": "GB/s", "bytes_per_position": 7760, "sizes": []}
+    rng = np.random.default_rng(0)
+    for N in (512, 1 << 20):
+        boards = np.zeros(N, dtype=L.BOARD_DTYPE)
+        boards["piece_occ"] = rng.integers(0, 2**63, (N, 6), dtype=np.uint64); boards["color_occ"] = rng.integers(0, 2**63, (N, 2), dtype=np.uint64)
+        boards["ply"] = rng.integers(0, 400, N); boards["ctm"] = rng.integers(0, 2, N); boards["castle_rights"] = rng.integers(0, 16, N)
+        d_b = torch.from_numpy(boards.view(np.uint8).reshape(N, 80)).cuda()
+        d_x = torch.empty((N, 1920), device="cuda", dtype=torch.float32)
+        torch.cuda.synchronize()
+        ms = C.c_float(0)
+        iters = 2000 if N <= 4096 else 20
+        for _ in range(2):
+            if lib.kh_time_encode_device(nn.handle, C.c_void_p(d_b.data_ptr()), N, C.c_void_p(d_x.data_ptr()), iters, C.byref(ms)):
+                raise RuntimeError(L.last_error())
+        gbs = N * 7760 / (ms.value * 1e-3) / 1e9
+        out["sizes"].append({"positions": N, "us_per_launch": round(ms.value * 1e3, 3), "positions_per_s": round(N / (ms.value * 1e-3), 1),
+                             "achieved": round(gbs, 1), "frac": round(gbs / 8000.0, 4)})
+        del d_b, d_x
+    out["achieved"], out["frac"] = out["sizes"][-1]["achieved"], out["sizes"][-1]["frac"]
+    out["note"] = "512 positions (3.9 MB) is one launch's latency, not bandwidth; the roofline figure is the 2^20-position stream"
+    return out
+
+
+def configs0_leg(NN, W, L, device):
+    """BASELINE configs[0]'s shape — 1 self-play game, 64 MCTS sims per move, one leaf per evaluation — on the engine
+    (the reference runs it with its CPU NN::infer: ~64 positions/s, BASELINE.md section 2).  Host search + batch-1
+    evaluations through kh_encode_infer_legal; the net is options.def.yml's default 2 x 64."""
+    from kami_amd import search as S
+    nn = NN(8, 8, 30, 4672, filters=64, residuals=2, dtype="bf16", device=device, value_mode=L.KH_VALUE_PER_SAMPLE0)
+    nn.load_weights(W.random_weights(30, 64, 2, seed=1, peaky=5.0), 1)
+    pool = S.Pool(nn, games=1, threads=1, nodes=64, leaves_per_tree=1, seed=1)
+    pool.run(min_evals=2000, max_seconds=5.0)
+    s0 = pool.run(min_evals=0, max_seconds=0.0)
+    st = pool.run(min_evals=10**12, max_seconds=2.0)
+    de, dm, dt = st.evals - s0.evals, st.moves - s0.moves, st.seconds - s0.seconds
+    pool.close()
+    return {"workload": "1 self-play game, 64 MCTS sims per move, batch-1 leaf evaluations, 2x64 net, one host thread (BASELINE configs[0]'s shape)",
+            "positions_per_s": round(dm / dt, 1), "leaf_evals_per_s": round(de / dt, 1), "us_per_eval_call": round(dt / max(1, de) * 1e6, 2),
+            "reference_cpu_positions_per_s": 64, "reference_source": "BASELINE.md section 2 (reference Selfplay, CPU NN::infer, survey container)"}
+
+
 def pcie_probe():
     """What the host link of this box moves between page-locked host memory and HBM: each direction alone, and both at once
     (kh_infer needs both: planes in while policies go out)."""
@@ -392,10 +442,17 @@ def main():
     dt = time.perf_counter() - t0
     dt = kd.max_over_ranks(dist, dt)
     assert bool(torch.isfinite(policy).all()) and abs(float(policy[0].sum()) - 1.0) < 1e-2
+    # the timed entry point against the host-buffer call of the same engine (the one the parity tests pin to the
+    # reference's fixtures and the oracle): sampled rows, bit for bit
+    rows = sorted({0, 1, B // 2, B - 2, B - 1} | {int(i) for i in np.random.default_rng(1).integers(0, B, 11)})
+    ref_p, ref_v, _ = nn.infer_full(x[rows].cpu().numpy(), want_logits=False)
+    got_p, got_v = policy[rows].cpu().numpy(), vfull[rows].cpu().numpy()
+    if not (np.array_equal(got_p.view(np.uint32), ref_p.view(np.uint32)) and np.array_equal(got_v.view(np.uint32), ref_v.view(np.uint32))):
+        raise RuntimeError("bench: the timed kh_infer_device output differs from kh_infer_full on the same rows")
 
     # distribution: `repeats` separately synchronised bursts of the same step (after the timed region: a sync per
-    # burst would perturb `value`), each long enough (>= 2 ms) that the synchronise does not dominate
-    per = max(1, min(a.steps, max(20, int(2.0 / max(dt / a.steps * 1e3, 1e-3)))))
+    # burst would perturb `value`), each long enough (>= 2 ms, whatever --steps was) that the synchronise does not dominate
+    per = max(20, int(2.0 / max(dt / a.steps * 1e3, 1e-3)))
     for _ in range(a.warmup):
         step()
     torch.cuda.synchronize()
@@ -432,9 +489,19 @@ def main():
             "distribution": {"unit": "leaf-evals/s per GPU (this rank)", "repeats": len(rates), "steps_per_repeat": per,
                              "p10": round(pct(0.10), 1), "median": round(pct(0.50), 1), "p90": round(pct(0.90), 1)},
         }
-        if world == 1 and not a.no_variants:
+        if world == 1:
             del leg
             torch.cuda.empty_cache()
+            f32 = DeviceLeg(torch, lib, NN, W, "f32", F, Cc, R, B, 7, dev_index)
+            ms32, _ = f32.settled_ms(a.prewarm, 0.4)
+            out["value_f32"] = round(B / (ms32 * 1e-3), 1)
+            out["roofline_f32"] = f32.roofline(ms32)
+            out["roofline_f32"]["note"] = "the same step in the reference's own arithmetic: exact fp32 on v_mfma_f32_32x32x2_f32 (layers_mfma.hip)"
+            del f32
+            torch.cuda.empty_cache()
+            out["encode"] = encode_leg(torch, lib, NN, L, dev_index)
+            out["configs0"] = configs0_leg(NN, W, L, dev_index)
+        if world == 1 and not a.no_variants:
             out["variants"] = variant_legs(torch, lib, NN, W, L, dev_index, a.prewarm)
             out["end_to_end"] = end_to_end_legs(NN, W, L, dev_index)
         if world == 1 and not a.no_cpu_baseline:

@@ -8,7 +8,7 @@ Per profiled command: the rocprofv3 --kernel-trace --stats table, and the per-di
 `roofline.traffic`: it carries the sha of the kernel sources it was collected on."""
 import csv, glob, hashlib, json, os, shutil, sys
 
-rnd = int(sys.argv[1]) if len(sys.argv) > 1 else 2
+rnd = int(sys.argv[1]) if len(sys.argv) > 1 else 3
 src, dst = "gpurun_out/prof", "profiles"
 tag = f"r{rnd:02d}"
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -81,7 +81,7 @@ rows = stats_rows("kt")
 write_stats(rows, f"{tag}_kernel_stats.csv")
 ctr = {}
 for d in ("pmc_fetch", "pmc_write", "pmc_sq"):
-    ctr.update(counters(d, "tower_kernel"))
+    ctr.update(counters(d, "tower8_kernel") or counters(d, "tower_kernel"))
 summary = {
     "round": rnd, "kernel_source_sha16": sha,
     "command": "rocprofv3 --kernel-trace --stats --output-format csv -- python3 bench.py --no-cpu-baseline --no-variants   (default --steps 2000 --warmup 200 --prewarm 0.3)",
@@ -92,13 +92,13 @@ summary = {
     "bench_line": {k: bench[k] for k in ("value", "ms_per_step", "roofline", "distribution") if k in bench},
     "counters": ctr,
 }
-tower = [r for r in rows if "tower_kernel" in r["Name"]]
+tower = [r for r in rows if "tower8_kernel" in r["Name"] or "tower_kernel" in r["Name"]]
 if tower:
     t = tower[0]
     summary["tower_kernel"] = {"name": t["Name"], "calls": int(t["Calls"]), "avg_ns": float(t["AverageNs"]), "min_ns": float(t["MinNs"]), "max_ns": float(t["MaxNs"])}
     trace = newest("kt/**/*kernel_trace.csv")
     if trace:
-        d = sorted((int(r["Start_Timestamp"]), int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) for r in csv.DictReader(open(trace)) if "tower_kernel" in r["Kernel_Name"])
+        d = sorted((int(r["Start_Timestamp"]), int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) for r in csv.DictReader(open(trace)) if "tower8_kernel" in r["Kernel_Name"] or "tower_kernel" in r["Kernel_Name"])
         last = [x[1] for x in d[-2000:]]
         summary["tower_kernel"]["avg_ns_last_2000_dispatches"] = sum(last) / len(last)
 tr = traffic(ctr, Bb * (64 * F * 4 + 4672 * 4 + 256 * 4))
