@@ -98,7 +98,13 @@ struct Value {
     std::vector<std::pair<VP, VP>> dict;                 // DICT and OBJECT state (insertion order)
     std::vector<int64_t> size, stride;                   // TENSOR
     int64_t offset = 0;
+    // Hostile files: `depth` bounds the nesting (the shared_ptr graph is torn down recursively: 300 000 nested TUPLE1s
+    // used to overflow the stack in the destructor), `sealed` is set once a value has become a child of a container
+    // and forbids changing it afterwards — what libtorch's pickler never does, and the only way to close a cycle.
+    int depth = 0;
+    bool sealed = false;
 };
+constexpr int MAX_NESTING = 64;
 inline VP mk(Value::Kind k) { auto v = std::make_shared<Value>(); v->kind = k; return v; }
 
 inline VP unpickle(const uint8_t* d, size_t n)
@@ -117,6 +123,19 @@ inline VP unpickle(const uint8_t* d, size_t n)
         return items;
     };
     auto integer = [&](int64_t v) { VP x = mk(Value::INT); x->i = v; st.push_back(x); };
+    // child -> container: depth bookkeeping, nesting bound, and the child may not be changed any more
+    auto adopt = [&](Value& box, const VP& child) {
+        if (child.get() == &box) bad("pickle: a container inside itself");
+        if (child->depth + 1 > MAX_NESTING) bad("pickle: nesting deeper than 64 levels");
+        if (child->depth + 1 > box.depth) box.depth = child->depth + 1;
+        child->sealed = true;
+    };
+    auto open_box = [&](Value::Kind k, const char* what) -> Value& {
+        if (st.empty() || st.back()->kind != k) bad(std::string("pickle: ") + what);
+        if (st.back()->sealed) bad(std::string("pickle: ") + what + " on a container that is already part of another");
+        return *st.back();
+    };
+    if (n > ((size_t)64 << 20)) bad("pickle larger than 64 MB");
     while (i < n) {
         const uint8_t op = d[i++];
         switch (op) {
@@ -156,11 +175,13 @@ inline VP unpickle(const uint8_t* d, size_t n)
         case 0x88: { VP b = mk(Value::BOOL); b->i = 1; st.push_back(b); break; }
         case 0x89: st.push_back(mk(Value::BOOL)); break;
         case 0x4e: st.push_back(mk(Value::NONE)); break;
-        case 0x74: { VP t = mk(Value::TUPLE); t->items = pop_mark(); st.push_back(t); break; }
+        case 0x74: { VP t = mk(Value::TUPLE); t->items = pop_mark(); for (auto& v : t->items) adopt(*t, v); st.push_back(t); break; }
         case 0x85: case 0x86: case 0x87: {
             const size_t k = op - 0x84;
             if (st.size() < k) bad("pickle: TUPLEn");
-            VP t = mk(Value::TUPLE); t->items.assign(st.end() - k, st.end()); st.resize(st.size() - k); st.push_back(t); break;
+            VP t = mk(Value::TUPLE); t->items.assign(st.end() - k, st.end()); st.resize(st.size() - k);
+            for (auto& v : t->items) adopt(*t, v);
+            st.push_back(t); break;
         }
         case 0x81: {                                                                                         // NEWOBJ
             VP args = pop(), cls = pop();
@@ -196,17 +217,20 @@ inline VP unpickle(const uint8_t* d, size_t n)
         }
         case 0x75: {                                                                                         // SETITEMS
             auto items = pop_mark();
-            if (st.empty() || st.back()->kind != Value::DICT || (items.size() & 1)) bad("pickle: SETITEMS");
-            for (size_t k = 0; k < items.size(); k += 2) st.back()->dict.emplace_back(items[k], items[k + 1]);
+            Value& box = open_box(Value::DICT, "SETITEMS");
+            if (items.size() & 1) bad("pickle: SETITEMS");
+            for (size_t k = 0; k < items.size(); k += 2) { adopt(box, items[k]); adopt(box, items[k + 1]); box.dict.emplace_back(items[k], items[k + 1]); }
             break;
         }
-        case 0x73: { VP v = pop(), k = pop(); if (st.empty() || st.back()->kind != Value::DICT) bad("pickle: SETITEM"); st.back()->dict.emplace_back(k, v); break; }
-        case 0x65: { auto items = pop_mark(); if (st.empty() || st.back()->kind != Value::LIST) bad("pickle: APPENDS"); for (auto& v : items) st.back()->items.push_back(v); break; }
-        case 0x61: { VP v = pop(); if (st.empty() || st.back()->kind != Value::LIST) bad("pickle: APPEND"); st.back()->items.push_back(v); break; }
+        case 0x73: { VP v = pop(), k = pop(); Value& box = open_box(Value::DICT, "SETITEM"); adopt(box, k); adopt(box, v); box.dict.emplace_back(k, v); break; }
+        case 0x65: { auto items = pop_mark(); Value& box = open_box(Value::LIST, "APPENDS"); for (auto& v : items) { adopt(box, v); box.items.push_back(v); } break; }
+        case 0x61: { VP v = pop(); Value& box = open_box(Value::LIST, "APPEND"); adopt(box, v); box.items.push_back(v); break; }
         case 0x62: {                                                                                         // BUILD
             VP state = pop();
-            if (st.empty() || st.back()->kind != Value::OBJECT || state->kind != Value::DICT) bad("pickle: BUILD");
-            st.back()->dict = state->dict; break;
+            Value& box = open_box(Value::OBJECT, "BUILD");
+            if (state->kind != Value::DICT) bad("pickle: BUILD");
+            for (auto& kv : state->dict) { adopt(box, kv.first); adopt(box, kv.second); }     // (the state's children become the object's)
+            box.dict = state->dict; break;
         }
         case 0x2e: return pop();                                                                             // STOP
         default: { char b[80]; snprintf(b, sizeof b, "pickle opcode 0x%02x is not one libtorch's module pickler writes", op); bad(b); }

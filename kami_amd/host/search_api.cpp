@@ -11,6 +11,7 @@
 #include <cstdio>
 #include <mutex>
 #include <string>
+#include <set>
 #include <thread>
 
 using namespace kami;
@@ -376,12 +377,25 @@ int ks_pool_create(kh_engine* engine, const ks_pool_config* cfg, ks_pool** out)
     ks_pool* p = new ks_pool();
     p->engine = engine;
     p->cfg = *cfg;
-    if (cfg->pipeline && kh_set_coalesce(engine, cfg->coalesce_target, cfg->coalesce_wait_us) != KH_OK) {
-        delete p;
-        return fail("%s", kh_last_error());
+    if (cfg->pipeline) {
+        // The queue's limits (include/kami_hip.h: a submission holds at most 512 positions, an engine at most
+        // KH_MAX_OUTSTANDING un-waited tickets), checked here instead of failing inside every worker's first round.
+        const int T = std::min(cfg->threads, cfg->games), sets = std::min(4, std::max(2, cfg->pipeline));
+        const int per_set = ((cfg->games + T - 1) / T + sets - 1) / sets * std::max(1, cfg->leaves_per_tree);
+        if (per_set > 512) {
+            delete p;
+            return fail("pipelined pool: %d games / %d threads / %d sets x %d leaves per tree = %d positions per submission, the queue takes 512: "
+                        "more threads or sets, fewer leaves per tree, or pipeline = 0", cfg->games, T, sets, cfg->leaves_per_tree, per_set);
+        }
+        if (T * sets > KH_MAX_OUTSTANDING) {
+            delete p;
+            return fail("pipelined pool: %d threads x %d sets in flight exceed the engine's %d outstanding tickets", T, sets, KH_MAX_OUTSTANDING);
+        }
+        if (cfg->coalesce_target < 0 || cfg->coalesce_target > 1024 || cfg->coalesce_wait_us < 0 || cfg->coalesce_wait_us > 1000000) {
+            delete p;
+            return fail("coalesce_target in [0, 1024], coalesce_wait_us in [0, 1000000]");
+        }
     }
-    // every worker submits one set per round: a launch that holds a submission of each is a whole round
-    if (cfg->pipeline && cfg->coalesce_target > 0) (void)kh_set_coalesce_callers(engine, std::min(cfg->threads, cfg->games));
     p->games.resize((size_t)cfg->games);
     for (int i = 0; i < cfg->games; ++i) {
         MCTSConfig mc;
@@ -394,11 +408,40 @@ int ks_pool_create(kh_engine* engine, const ks_pool_config* cfg, ks_pool** out)
     return 0;
 }
 
+// engines that a pipelined pool is running on right now: the queue's merge settings are per ENGINE, so two such pools
+// on one engine would overwrite each other's
+static std::mutex g_pipe_mu;
+static std::set<const kh_engine*> g_pipe_engines;
+
 int ks_pool_run(ks_pool* p, int64_t min_evals, double max_seconds, ks_pool_stats* stats)
 {
     const auto t0 = std::chrono::steady_clock::now();
     const int T = std::min(p->cfg.threads, p->cfg.games);
     p->error.clear();
+    // The engine's merge settings belong to this run only: set here, put back to "launch at once" before returning (a
+    // later synchronous small call must not wait out this pool's quiet period, and ks_pool_destroy never touches the
+    // engine: it may be gone by then).
+    struct PipeGuard {
+        kh_engine* e = nullptr;
+        ~PipeGuard()
+        {
+            if (!e) return;
+            (void)kh_set_coalesce_callers(e, 0);
+            (void)kh_set_coalesce(e, 0, 0);
+            std::lock_guard<std::mutex> lk(g_pipe_mu);
+            g_pipe_engines.erase(e);
+        }
+    } guard;
+    if (p->cfg.pipeline) {
+        {
+            std::lock_guard<std::mutex> lk(g_pipe_mu);
+            if (!g_pipe_engines.insert(p->engine).second) return fail("another pipelined pool is running on this engine (the queue's merge settings are per engine)");
+        }
+        guard.e = p->engine;
+        if (kh_set_coalesce(p->engine, p->cfg.coalesce_target, p->cfg.coalesce_wait_us) != KH_OK) return fail("%s", kh_last_error());
+        // every worker submits one set per round: a launch that holds a submission of each is a whole round
+        if (p->cfg.coalesce_target > 0) (void)kh_set_coalesce_callers(p->engine, T);
+    }
     const int64_t target = p->evals.load() + min_evals;
     std::vector<std::thread> th;
     for (int t = 0; t < T; ++t) {
@@ -432,8 +475,7 @@ int64_t ks_pool_drain_records(ks_pool* p, ks_record* out, int64_t cap)
 
 void ks_pool_destroy(ks_pool* p)
 {
-    if (p && p->cfg.pipeline && p->cfg.coalesce_target > 0) (void)kh_set_coalesce_callers(p->engine, 0);
-    delete p;
+    delete p;       // (never touches the engine: it may have been destroyed before its pools)
 }
 
 }  // extern "C"

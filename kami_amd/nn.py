@@ -69,8 +69,16 @@ import weakref
 _LIVE = weakref.WeakSet()
 
 
+def _close_pools(nn=None):
+    import sys
+    search = sys.modules.get(__package__ + ".search")
+    if search is not None:
+        search.close_pools_of(nn)
+
+
 @atexit.register
 def _close_all():
+    _close_pools()                      # pools first: they hold engine handles
     for nn in list(_LIVE):
         try:
             nn.close()
@@ -265,6 +273,7 @@ class NN:
 
     def close(self) -> None:
         if getattr(self, "_h", None):
+            _close_pools(self)          # a self-play pool on this engine is closed with it
             self._lib.kh_destroy(self._h)
             self._h = None
 

@@ -153,6 +153,18 @@ def mcts_synthetic(nodes: int, nmoves: int, leaves: int = 1, picks=None) -> str:
     return buf.value.decode()
 
 
+import weakref
+
+_POOLS = weakref.WeakSet()      # live pools: closed before their engines (kami_amd.nn._close_all, NN.close)
+
+
+def close_pools_of(nn=None):
+    """Close every live pool (of engine `nn`, or of any engine): a pool must not outlive the engine it feeds."""
+    for pool in list(_POOLS):
+        if nn is None or pool.nn is nn:
+            pool.close()
+
+
 class Pool:
     """Self-play pool (kami/selfplay.cpp:58-213) feeding an engine (kami_amd.NN) with compact records."""
 
@@ -165,9 +177,13 @@ class Pool:
                          alpha_cutoff, draw_value_pct, seed, int(pipeline), coalesce_target, coalesce_wait_us)   # pipeline: False / True (two sets) / 2..4 sets
         self.h = C.c_void_p()
         if self.lib.ks_pool_create(nn.handle, C.byref(cfg), C.byref(self.h)):
+            self.h = None
             raise RuntimeError(self.lib.ks_last_error().decode())
+        _POOLS.add(self)
 
     def run(self, min_evals=0, max_seconds=1.0):
+        if not getattr(self, "h", None):
+            raise RuntimeError("the pool is closed (its engine was closed)")
         st = PoolStats()
         if self.lib.ks_pool_run(self.h, int(min_evals), float(max_seconds), C.byref(st)):
             raise RuntimeError(self.lib.ks_last_error().decode())

@@ -146,10 +146,33 @@ def test_checkpoint_readers_survive_a_module_that_contains_itself(tmp_path):
     pkl = b"\x80\x02c__torch__.M\nM\n)\x81q\x00}(" + s(b"me") + b"h\x00ub."
     p = str(tmp_path / "cycle.pt")
     _hostile_archive(p, pkl)
-    with pytest.raises(KamiError, match="too deep"):
+    with pytest.raises(KamiError, match="too deep|already part of another"):
         read_checkpoint(p)
     with pytest.raises(TA.ArchiveError, match="too deep"):
         TA.read_archive(p)
+
+
+def test_checkpoint_readers_survive_300000_nested_tuples(tmp_path):
+    """A 300 KB data.pkl of ')' + 300 000 TUPLE1 + STOP nests a value 300 000 levels deep: the C++ reader's value graph
+    is torn down recursively, so it bounds the nesting while parsing (it used to overflow the stack in the destructor
+    after refusing the file); the Python twin refuses the root."""
+    from kami_amd import KamiError, torch_archive as TA
+    from kami_amd.nn import read_checkpoint
+    p = str(tmp_path / "deep.pt")
+    _hostile_archive(p, b"\x80\x02)" + b"\x85" * 300000 + b".")
+    with pytest.raises(KamiError, match="nesting deeper"):
+        read_checkpoint(p)
+    with pytest.raises(TA.ArchiveError):
+        TA.read_archive(p)
+    # the same depth through lists, dicts and a module's state
+    s = lambda t: b"X" + len(t).to_bytes(4, "little") + t
+    for pkl in (b"\x80\x02" + b"]" * 100000 + b"a" * 99999 + b".",
+                b"\x80\x02" + (b"}" + s(b"k")) * 5000 + b"N" + b"s" * 5000 + b"."):
+        _hostile_archive(p, pkl)
+        with pytest.raises(KamiError, match="nesting deeper|not a module"):
+            read_checkpoint(p)
+        with pytest.raises(TA.ArchiveError):
+            TA.read_archive(p)
 
 
 def test_checkpoint_readers_survive_mutated_archives(tmp_path):
