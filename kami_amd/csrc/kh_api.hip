@@ -1578,13 +1578,19 @@ int kh_checkpoint_read(const char* path, int* features, int* filters, int* resid
             auto g = ck.ints.find("generation");
             if (w == ck.tensors.end() || w->second.shape.size() != 4 || g == ck.ints.end())
                 return fail(KH_ERR_INVALID, "%s: not a kami checkpoint (no conv1.weight / generation)", path);
-            C = (int)w->second.shape[0]; F = (int)w->second.shape[1]; gen = (int)g->second;
-            while (ck.tensors.count("residual" + std::to_string(R) + ".conv1.weight")) ++R;
+            // the same bounds as the KAMW path, on numbers that come from the file; every tensor below must have EXACTLY
+            // the shape libtorch gives it (nn.cpp:20-23,45-56) — an element count alone would take a transposed tensor
+            const int64_t c64 = w->second.shape[0], f64 = w->second.shape[1];
+            if (f64 < 1 || f64 > 4096 || c64 < 1 || c64 > 1024) return fail(KH_ERR_INVALID, "%s: conv1.weight has an impossible shape", path);
+            if (g->second < INT32_MIN || g->second > INT32_MAX) return fail(KH_ERR_INVALID, "%s: generation out of range", path);
+            C = (int)c64; F = (int)f64; gen = (int)g->second;
+            while (R <= 256 && ck.tensors.count("residual" + std::to_string(R) + ".conv1.weight")) ++R;
+            if (R > 256) return fail(KH_ERR_INVALID, "%s: more than 256 residual blocks", path);
             // blob order of kh_weight_count (names per nn.cpp:20-23,45-56)
-            std::vector<std::pair<std::string, size_t>> order;
-            auto convbn = [&](const std::string& conv, const std::string& bn, size_t co, size_t ci, size_t k) {
-                order.emplace_back(conv + ".weight", co * ci * k * k); order.emplace_back(conv + ".bias", co);
-                for (const char* s : { ".weight", ".bias", ".running_mean", ".running_var" }) order.emplace_back(bn + s, co);
+            std::vector<std::pair<std::string, std::vector<int64_t>>> order;
+            auto convbn = [&](const std::string& conv, const std::string& bn, int64_t co, int64_t ci, int64_t k) {
+                order.emplace_back(conv + ".weight", std::vector<int64_t>{ co, ci, k, k }); order.emplace_back(conv + ".bias", std::vector<int64_t>{ co });
+                for (const char* s : { ".weight", ".bias", ".running_mean", ".running_var" }) order.emplace_back(bn + s, std::vector<int64_t>{ co });
             };
             convbn("conv1", "batchnorm1", C, F, 3);
             for (int i = 0; i < R; ++i) {
@@ -1593,17 +1599,17 @@ int kh_checkpoint_read(const char* path, int* features, int* filters, int* resid
                 convbn(r + ".conv2", r + ".batchnorm2", C, C, 3);
             }
             convbn("policyconv", "pbatchnorm", KH_POLICY_MID, C, 1);
-            order.emplace_back("policyconv2.weight", (size_t)KH_POLICY_PLANES * KH_POLICY_MID);
-            order.emplace_back("policyconv2.bias", KH_POLICY_PLANES);
+            order.emplace_back("policyconv2.weight", std::vector<int64_t>{ KH_POLICY_PLANES, KH_POLICY_MID, 1, 1 });
+            order.emplace_back("policyconv2.bias", std::vector<int64_t>{ KH_POLICY_PLANES });
             convbn("valueconv", "vbatchnorm", 1, C, 1);
-            order.emplace_back("valuefc.weight", (size_t)KH_VALUE_WIDTH * 64);
-            order.emplace_back("valuefc.bias", KH_VALUE_WIDTH);
+            order.emplace_back("valuefc.weight", std::vector<int64_t>{ KH_VALUE_WIDTH, 64 });
+            order.emplace_back("valuefc.bias", std::vector<int64_t>{ KH_VALUE_WIDTH });
             if (order.size() != ck.tensors.size())
                 return fail(KH_ERR_INVALID, "%s: %zu tensors, this network has %zu", path, ck.tensors.size(), order.size());
             for (auto& o : order) {
                 auto t = ck.tensors.find(o.first);
-                if (t == ck.tensors.end() || t->second.data.size() != o.second)
-                    return fail(KH_ERR_INVALID, "%s: tensor %s missing or of the wrong size", path, o.first.c_str());
+                if (t == ck.tensors.end() || t->second.shape != o.second)
+                    return fail(KH_ERR_INVALID, "%s: tensor %s missing or of the wrong shape", path, o.first.c_str());
                 data.insert(data.end(), t->second.data.begin(), t->second.data.end());
             }
         } catch (const std::exception& ex) {

@@ -1736,10 +1736,14 @@ template <typename T> static hipError_t run(const LayersArgs& L, hipStream_t s)
     // reading the fp32 planes itself.  One workgroup per four boards: worth it once that keeps most CUs busy.
     const bool fused = L.FP == 128 && L.CP == 128 && L.w4 && L.w4_off[0] != (size_t)-1 && force != 6 && (force == 5 || (!force && L.B >= 640));
     const bool direct = fused && (reinterpret_cast<uintptr_t>(L.in) & 15) == 0;
-    const bool direct256 = (reinterpret_cast<uintptr_t>(L.in) & 15) == 0 && L.FP == 128 &&
-                           ((L.CP == 256 && L.w2b && (force == 6 || (!force && L.B >= 384))) ||
-                            (L.CP == 128 && L.w4 && L.w4_off[0] != (size_t)-1 && (force == 6 || (!force && L.B >= 256 && !fused))));
-    if (!direct && !direct256) hipLaunchKernelGGL(planes_to_act_kernel<T>, dim3(blocks), dim3(256), 0, s, L.in, L.act_in, npix, L.F, L.FP);
+    // two boards per workgroup, waves own output channels (tower2b_kernel): 256 filters from batch 256 on; 128 filters
+    // for the batches where tower128_kernel's four boards per workgroup do not fill the chip (KAMI_WIDE_VARIANT=6 forces it).
+    // It reads the fp32 planes itself: ONE condition decides both that and whether planes_to_act_kernel runs (they used to
+    // disagree for 256 filters at 256 <= batch < 384: a launch whose output nobody read).
+    const bool aligned = (reinterpret_cast<uintptr_t>(L.in) & 15) == 0;
+    const bool fused256 = aligned && L.FP == 128 && ((L.CP == 256 && L.w2b && (force == 6 || (!force && L.B >= 256))) ||
+                                                      (L.CP == 128 && L.w4 && L.w4_off[0] != (size_t)-1 && (force == 6 || (!force && L.B >= 256 && !fused))));
+    if (!direct && !fused256) hipLaunchKernelGGL(planes_to_act_kernel<T>, dim3(blocks), dim3(256), 0, s, L.in, L.act_in, npix, L.F, L.FP);
     unsigned short *x = L.act[0], *t = L.act[1], *u = L.act[2];
     hipError_t e;
     size_t li = 0;
@@ -1748,11 +1752,6 @@ template <typename T> static hipError_t run(const LayersArgs& L, hipStream_t s)
     auto shift = [&](int idx) { return L.shift + L.shift_off[idx]; };
     ConvArgs a;
     a.B = L.B;
-    // two boards per workgroup, waves own output channels (tower2b_kernel): 256 filters from batch 256 on; 128 filters
-    // for the batches where tower128_kernel's four boards per workgroup do not fill the chip (KAMI_WIDE_VARIANT=6 forces it)
-    const bool aligned = (reinterpret_cast<uintptr_t>(L.in) & 15) == 0;
-    const bool fused256 = aligned && L.FP == 128 && ((L.CP == 256 && L.w2b && (force == 6 || (!force && L.B >= 256))) ||
-                                                      (L.CP == 128 && L.w4 && L.w4_off[0] != (size_t)-1 && (force == 6 || (!force && L.B >= 256 && !fused))));
     if (fused256) {
         static std::atomic<bool> attr_done{ false };
         if (!attr_done.load(std::memory_order_acquire)) {

@@ -223,3 +223,73 @@ def test_weight_container_header_is_bounded_before_anything_is_sized(tmp_path):
         with pytest.raises(ValueError):
             W.load(p)
         assert time.time() - t0 < 1.0
+
+
+
+def _write_module_archive(path, tensors, ints):
+    """A libtorch-style archive written by hand: `tensors` name -> fp32 array ('a.b.weight' nests modules a, b), `ints`
+    top-level integer attributes.  Protocol-2 pickle of __torch__ module objects, one storage member per tensor."""
+    s = lambda t: b"X" + len(t).to_bytes(4, "little") + t
+    num = lambda v: b"\x8a\x08" + int(v).to_bytes(8, "little", signed=True)
+    tup = lambda vals: b"(" + b"".join(num(v) for v in vals) + b"t"
+    storages = {}
+
+    def tensor(arr):
+        key = str(len(storages)).encode()
+        storages[key] = np.ascontiguousarray(arr, dtype=np.float32).tobytes()
+        strides = [int(np.prod(arr.shape[i + 1:])) for i in range(arr.ndim)]
+        storage = b"(" + s(b"storage") + b"ctorch\nFloatStorage\n" + s(key) + s(b"cpu") + num(arr.size) + b"tQ"
+        return (b"ctorch._utils\n_rebuild_tensor_v2\n(" + storage + num(0) + tup(arr.shape) + tup(strides) + b"\x89" +
+                b"ccollections\nOrderedDict\n)R" + b"tR")
+    tree = {}
+    for name, arr in tensors.items():
+        cur = tree
+        *path_, leaf = name.split(".")
+        for part in path_:
+            cur = cur.setdefault(part, {})
+        cur[leaf] = arr
+
+    def module(d, extra=()):
+        body = b"".join(s(k.encode()) + (module(v) if isinstance(v, dict) else tensor(v)) for k, v in d.items())
+        body += b"".join(s(k.encode()) + num(v) for k, v in extra)
+        return b"c__torch__.M\nM\n)\x81}(" + body + b"ub"
+    pkl = b"\x80\x02" + module(tree, tuple(ints.items())) + b"."
+    with zipfile.ZipFile(path, "w", zipfile.ZIP_STORED) as z:
+        z.writestr("m/data.pkl", pkl)
+        for key, raw in storages.items():
+            z.writestr("m/data/" + key.decode(), raw)
+        z.writestr("m/version", b"3\n")
+
+
+def test_checkpoint_readers_compare_whole_shapes_and_bound_their_numbers(tmp_path):
+    """A tensor with the right element count but another shape ([C, 9 F, 1, 1] for conv1.weight, a transposed valuefc) is
+    not the network's: both readers compare whole shapes (the C reader used to match element counts only) and range-check
+    the generation; the hand-written archive of the right shapes is read back bit for bit by both."""
+    from kami_amd import KamiError, torch_archive as TA, weights as W
+    from kami_amd.nn import read_checkpoint
+    F, Cc, R = 30, 8, 1
+    blob = W.random_weights(F, Cc, R, seed=2)
+
+    def tensors():
+        out, off = {}, 0
+        for n, shape in W.tensor_specs(F, Cc, R):
+            k = int(np.prod(shape)); out[n] = blob[off:off + k].reshape(shape).copy(); off += k
+        return out
+    p = str(tmp_path / "a.pt")
+    _write_module_archive(p, tensors(), {"generation": 7})
+    got, f, c, r, gen = read_checkpoint(p)
+    assert (f, c, r, gen) == (F, Cc, R, 7) and np.array_equal(got.view(np.uint32), blob.view(np.uint32))
+    got2 = TA.load_reference_checkpoint(p)
+    assert np.array_equal(np.asarray(got2[0]).view(np.uint32), blob.view(np.uint32))
+    for name, new_shape in (("conv1.weight", (Cc, 9 * F, 1, 1)), ("valuefc.weight", (64, 256)), ("policyconv2.weight", (73 * 128, 1, 1, 1)),
+                            ("residual0.conv2.weight", (Cc * Cc, 3, 3))):
+        t = tensors()
+        t[name] = t[name].reshape(new_shape)
+        _write_module_archive(p, t, {"generation": 7})
+        with pytest.raises(KamiError, match="shape|rank|checkpoint"):
+            read_checkpoint(p)
+        with pytest.raises(TA.ArchiveError):
+            TA.load_reference_checkpoint(p)
+    _write_module_archive(p, tensors(), {"generation": 1 << 40})
+    with pytest.raises(KamiError, match="generation out of range"):
+        read_checkpoint(p)
