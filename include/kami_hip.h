@@ -116,10 +116,20 @@ typedef struct kh_train_config {
     float   lr;             /* "training_mlr" / 1000  (nn.cpp:236)  */
     int32_t epochs;         /* "training_epochs"       (nn.cpp:237)  */
     int32_t batch;          /* "training_batchsize"    (nn.cpp:238)  */
-    int32_t reserved[5];
+    int32_t detect_anomaly; /* NN::train's last argument (nn.cpp:224,231-232,329-344): nonzero = every batch is checked — its
+                               input for NaN before the step, the forward's value and policy outputs behind it — and kh_train
+                               fails with the reference's messages "training input ind <i> contains NaN" (KH_ERR_INVALID),
+                               "forward value output contains NaN" (KH_ERR_NAN_VALUE), "forward policy output contains NaN"
+                               (KH_ERR_NAN_POLICY); the parameters stay as they were before the call */
+    int32_t reserved[4];
 } kh_train_config;
 int  kh_train(kh_engine* e, const float* inputs, const float* obs_p, const float* obs_v, int trajectories,
               const kh_train_config* cfg, float* first_loss, float* last_loss);
+/* The order kh_train visits the samples in: order[epoch * trajectories + k] = index of the k-th sample of that epoch (one
+ * std::default_random_engine{} for the call, one std::shuffle per epoch: nn.cpp:245-262); consecutive runs of `batch` of
+ * them are the batches, a short last batch keeps the previous batch's rows behind its own (the reference's staging buffers
+ * persist).  No engine needed: what a restatement of a multi-batch run has to follow. */
+int  kh_train_order(int trajectories, int epochs, int32_t* order);
 
 /* NN::read nn.cpp:204-222: parse a checkpoint file without an engine.  Two containers are understood:
  * the reference's own — the libtorch archive NN::write leaves (nn.cpp:189-202: module.save + the

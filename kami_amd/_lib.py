@@ -33,7 +33,7 @@ assert BOARD_DTYPE.itemsize == 80
 # every symbol include/kami_hip.h declares: name -> (restype, argtypes)
 _P = C.c_void_p
 class TrainConfig(C.Structure):
-    _fields_ = [("lr", C.c_float), ("epochs", C.c_int32), ("batch", C.c_int32), ("reserved", C.c_int32 * 5)]
+    _fields_ = [("lr", C.c_float), ("epochs", C.c_int32), ("batch", C.c_int32), ("detect_anomaly", C.c_int32), ("reserved", C.c_int32 * 4)]
 
 
 SYMBOLS = {
@@ -42,6 +42,7 @@ SYMBOLS = {
     "kh_destroy": (None, [_P]),
     "kh_load_weights": (C.c_int, [_P, _P, C.c_size_t, C.c_int]),
     "kh_train": (C.c_int, [_P, _P, _P, _P, C.c_int, C.POINTER(TrainConfig), C.POINTER(C.c_float), C.POINTER(C.c_float)]),
+    "kh_train_order": (C.c_int, [C.c_int, C.c_int, _P]),
     "kh_checkpoint_read": (C.c_int, [C.c_char_p, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int),
                                      _P, C.c_size_t, C.POINTER(C.c_size_t)]),
     "kh_load_checkpoint": (C.c_int, [_P, C.c_char_p]),

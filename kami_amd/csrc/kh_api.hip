@@ -1461,7 +1461,7 @@ int kh_train(kh_engine* e, const float* inputs, const float* obs_p, const float*
         const void* before[3] = { params.p, work.p, dx.p };
         if ((rc = params.ensure(nfl * 4)) || (rc = grads.ensure(nfl * 4)) || (rc = work.ensure(kh::train_workspace_floats(F, C, R, B) * 4)) ||
             (rc = dx.ensure((size_t)B * 64 * F * 4)) || (rc = dp.ensure((size_t)B * KH_PSIZE * 4)) || (rc = dv.ensure((size_t)B * 4)) ||
-            (rc = dloss.ensure((size_t)B * 2 * 4)))
+            (rc = dloss.ensure((size_t)B * 2 * 4 + 8)))
             return rc;
         // the recorded step holds buffer addresses, the batch size, the learning rate and the kernel choice
         if (before[0] != params.p || before[1] != work.p || before[2] != dx.p || tc.B != B || tc.lr != cfg->lr || tc.valu != valu_now) tc.drop_graph();
@@ -1479,12 +1479,12 @@ int kh_train(kh_engine* e, const float* inputs, const float* obs_p, const float*
     // batch staging in page-locked memory (rows persist from batch to batch like the reference's stack buffers)
     PinMem& pin = tc.pin;
     const size_t n_in = (size_t)B * in_row, n_p = (size_t)B * KH_PSIZE;
-    if (pin.ensure((n_in + n_p + (size_t)B + (size_t)B * 2) * 4)) return KH_ERR_HIP;
+    if (pin.ensure((n_in + n_p + (size_t)B + (size_t)B * 2 + 2) * 4)) return KH_ERR_HIP;
     float* next_input = reinterpret_cast<float*>(pin.p);
     float* next_policy = next_input + n_in;
     float* next_value = next_policy + n_p;
     float* loss_rows = next_value + B;
-    memset(pin.p, 0, (n_in + n_p + (size_t)B + (size_t)B * 2) * 4);
+    memset(pin.p, 0, (n_in + n_p + (size_t)B + (size_t)B * 2 + 2) * 4);
     float firstloss = 0.0f, lastloss = 0.0f;
     const kh::StepBuffers sb{ params.as<float>(), grads.as<float>(), work.as<float>() };
     // A step is ~120 small launches on fixed buffers: recorded once as a graph, replayed per batch (with the
@@ -1506,6 +1506,10 @@ int kh_train(kh_engine* e, const float* inputs, const float* obs_p, const float*
                 next_value[i] = obs_v[src];
             }
             base += i;
+            if (cfg->detect_anomaly) {                        // nn.cpp:329-333: isnan on the batch as it goes to the device
+                for (size_t k = 0; k < n_in; ++k)
+                    if (next_input[k] != next_input[k]) return fail(KH_ERR_INVALID, "training input ind %d contains NaN", nbatches);
+            }
             HIPCHK(hipMemcpyAsync(dx.p, next_input, n_in * 4, hipMemcpyHostToDevice, st));
             HIPCHK(hipMemcpyAsync(dp.p, next_policy, n_p * 4, hipMemcpyHostToDevice, st));
             HIPCHK(hipMemcpyAsync(dv.p, next_value, (size_t)B * 4, hipMemcpyHostToDevice, st));
@@ -1525,8 +1529,13 @@ int kh_train(kh_engine* e, const float* inputs, const float* obs_p, const float*
             }
             if (graph.x) HIPCHK(hipGraphLaunch(graph.x, st));
             else HIPCHK(kh::train_step(*net, sb, dx.as<float>(), dp.as<float>(), dv.as<float>(), B, cfg->lr, dloss.as<float>(), st));
-            HIPCHK(hipMemcpyAsync(loss_rows, dloss.p, (size_t)B * 2 * 4, hipMemcpyDeviceToHost, st));
+            HIPCHK(hipMemcpyAsync(loss_rows, dloss.p, (size_t)B * 2 * 4 + 8, hipMemcpyDeviceToHost, st));
             HIPCHK(hipStreamSynchronize(st));
+            if (cfg->detect_anomaly) {                        // nn.cpp:337-341: the value output first, then the policy
+                const int* nf = reinterpret_cast<const int*>(loss_rows + 2 * B);
+                if (nf[1]) return fail(KH_ERR_NAN_VALUE, "forward value output contains NaN");
+                if (nf[0]) return fail(KH_ERR_NAN_POLICY, "forward policy output contains NaN");
+            }
             float lp = 0.0f, lv = 0.0f;
             for (int b = 0; b < B; ++b) { lp += loss_rows[b]; lv += loss_rows[B + b]; }
             const float loss = lp + lv / (float)(B * KH_VALUE_WIDTH);
@@ -1543,6 +1552,19 @@ int kh_train(kh_engine* e, const float* inputs, const float* obs_p, const float*
     if (first_loss) *first_loss = firstloss;
     if (last_loss) *last_loss = lastloss;
     return kh_load_weights(e, blob.data(), nfl, W->generation + 1);         // nn.cpp:371 ++generation
+}
+
+int kh_train_order(int trajectories, int epochs, int32_t* order)
+{
+    if (trajectories < 1 || epochs < 1 || !order) return fail(KH_ERR_INVALID, "trajectories >= 1, epochs >= 1 and a buffer required");
+    std::vector<int> picker((size_t)trajectories);
+    for (int i = 0; i < trajectories; ++i) picker[i] = i;
+    auto rng = std::default_random_engine{};                  // exactly kh_train's
+    for (int epoch = 0; epoch < epochs; ++epoch) {
+        std::shuffle(picker.begin(), picker.end(), rng);
+        for (int i = 0; i < trajectories; ++i) order[(size_t)epoch * trajectories + i] = picker[i];
+    }
+    return KH_OK;
 }
 
 int kh_checkpoint_read(const char* path, int* features, int* filters, int* residuals, int* generation,

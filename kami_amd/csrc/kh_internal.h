@@ -123,6 +123,6 @@ TrainNet* train_layout_new(int F, int C, int R);
 void train_layout_free(TrainNet* n);
 size_t train_workspace_floats(int F, int C, int R, int B);
 hipError_t train_step(const TrainNet& n, const StepBuffers& sb, const float* x_in, const float* obsp, const float* obsv,
-                      int B, float lr, float* loss_rows, hipStream_t s);
+                      int B, float lr, float* loss_rows /* [2 B] floats + 2 ints (NaN flags of the forward's outputs) */, hipStream_t s);
 
 }  // namespace kh

@@ -449,8 +449,9 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
 // ---- policy head tail: softmax over 4672 + policy loss and its gradient (nn.cpp:78-80, 99-103) ------
 // one workgroup per board; loss[b] = -sum obs_p * log(p + 0.001);  dlogit_i = p_i * (g_i - sum_j g_j p_j),
 // g_i = -obs_p_i / (p_i + 0.001)
+// nanflags[0]: a policy output is NaN (one NaN logit makes the row's log-sum, hence every entry, NaN: nn.cpp:340-341)
 __global__ __launch_bounds__(256) void policy_loss_kernel(const float* __restrict__ logits, const float* __restrict__ obsp,
-                                                          float* __restrict__ dlogits, float* __restrict__ loss_rows)
+                                                          float* __restrict__ dlogits, float* __restrict__ loss_rows, int* __restrict__ nanflags)
 {
     __shared__ float red[4];
     __shared__ float bc;
@@ -469,6 +470,7 @@ __global__ __launch_bounds__(256) void policy_loss_kernel(const float* __restric
     for (int i = tid; i < KH_PSIZE; i += 256) s += expf(x[i] - m);
     s = block_sum(s, red);
     const float ls = logf(s);
+    if (tid == 0 && ls != ls) atomicOr(&nanflags[0], 1);
     float loss = 0.0f, gp = 0.0f;
     for (int i = tid; i < KH_PSIZE; i += 256) {
         const float p = expf((x[i] - m) - ls);
@@ -491,7 +493,7 @@ __global__ __launch_bounds__(256) void policy_loss_kernel(const float* __restric
 // dpre[b][j] = 2 (v - obs_v[b]) / (B*256) * (1 - v^2);  sq[b] = sum_j (v - obs_v[b])^2
 __global__ __launch_bounds__(256) void value_fwd_loss_kernel(const float* __restrict__ h, const float* __restrict__ fcw,
                                                              const float* __restrict__ fcb, const float* __restrict__ obsv,
-                                                             float* __restrict__ dpre, float* __restrict__ sq_rows, int B)
+                                                             float* __restrict__ dpre, float* __restrict__ sq_rows, int B, int* __restrict__ nanflags)
 {
     __shared__ float hs[64];
     __shared__ float red[4];
@@ -501,6 +503,7 @@ __global__ __launch_bounds__(256) void value_fwd_loss_kernel(const float* __rest
     float acc = fcb[j];
     for (int k = 0; k < 64; ++k) acc = fmaf(hs[k], fcw[(size_t)j * 64 + k], acc);
     const float v = tanhf(acc), d = v - obsv[b];
+    if (v != v) atomicOr(&nanflags[1], 1);           // a value output is NaN (nn.cpp:337-338)
     dpre[(size_t)b * 256 + j] = 2.0f * d / (float)(B * 256) * (1.0f - v * v);
     const float sq = block_sum(d * d, red);
     if (j == 0) sq_rows[b] = sq;
@@ -611,8 +614,11 @@ size_t train_workspace_floats(int F, int C, int R, int B)
 }
 
 hipError_t train_step(const TrainNet& n, const StepBuffers& sb, const float* x_in, const float* obsp, const float* obsv,
-                      int B, float lr, float* loss_rows /* [2*B] device: policy rows, value squared-error rows */, hipStream_t s)
+                      int B, float lr, float* loss_rows /* [2*B] device: policy rows, value squared-error rows; behind them two ints:
+                      a policy / value output of this step's forward is NaN */, hipStream_t s)
 {
+    int* nanflags = reinterpret_cast<int*>(loss_rows + 2 * B);
+    (void)hipMemsetAsync(nanflags, 0, 2 * sizeof(int), s);
     const int C = n.C, N = B * 64;
     float* P = sb.params;
     float* G = sb.grads;
@@ -733,9 +739,9 @@ hipError_t train_step(const TrainNet& n, const StepBuffers& sb, const float* x_i
 
     // ---- losses and their gradients ----
     float* dlogits = take((size_t)B * KH_PSIZE);
-    hipLaunchKernelGGL(policy_loss_kernel, dim3(B), dim3(256), 0, s, logits, obsp, dlogits, loss_rows);
+    hipLaunchKernelGGL(policy_loss_kernel, dim3(B), dim3(256), 0, s, logits, obsp, dlogits, loss_rows, nanflags);
     float* dpre = take((size_t)B * 256);
-    hipLaunchKernelGGL(value_fwd_loss_kernel, dim3(B), dim3(256), 0, s, h, P + n.fcw, P + n.fcb, obsv, dpre, loss_rows + B, B);
+    hipLaunchKernelGGL(value_fwd_loss_kernel, dim3(B), dim3(256), 0, s, h, P + n.fcw, P + n.fcb, obsv, dpre, loss_rows + B, B, nanflags);
 
     // ---- backward ----
     wpart = take(train_wgrad_part_floats(n.F, C, B));

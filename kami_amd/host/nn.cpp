@@ -121,6 +121,10 @@ NN::NN(int width, int height, int features, int psize, bool force_cpu) :
         dtype = KH_F32;
     }
     create(dtype);
+    // the reference computes in fp32; this engine's DEFAULT is bf16 operands with fp32 accumulation (option key
+    // "engine_dtype": f32 | f16 | bf16) — said once per model so that nobody compares numerics unknowingly
+    std::cerr << "kami::NN: MI355X engine, " << (dtype == KH_F32 ? "fp32 (exact, the reference's arithmetic)" : dtype == KH_F16 ? "f16 operands, fp32 accumulate" : "bf16 operands, fp32 accumulate")
+              << " [engine_dtype], device " << device.index << "\n";
     std::vector<float> b = fresh_blob(features, filters, residuals);
     load_blob(b.data(), b.size(), 0);
 }
@@ -150,7 +154,7 @@ void NN::infer(float* input, int batch, float* policy, float* value)
     if (rc) raise(rc);
 }
 
-void NN::train(int trajectories, float* inputs, float* obs_p, float* obs_v, bool)
+void NN::train(int trajectories, float* inputs, float* obs_p, float* obs_v, bool detect_anomaly)
 {
     // nn.cpp:236-238: the three option keys the reference reads
     kh_train_config cfg;
@@ -158,6 +162,7 @@ void NN::train(int trajectories, float* inputs, float* obs_p, float* obs_v, bool
     cfg.lr = (float)options::getInt("training_mlr", 5) / 1000.0f;
     cfg.epochs = options::getInt("training_epochs", 8);
     cfg.batch = options::getInt("training_batchsize", 8);
+    cfg.detect_anomaly = detect_anomaly ? 1 : 0;                 // nn.cpp:231-232,329-344: the same three messages
     float first = 0.0f, last = 0.0f;
     int rc = kh_train(eng, inputs, obs_p, obs_v, trajectories, &cfg, &first, &last);
     if (rc) raise(rc);

@@ -105,15 +105,17 @@ class NN:
         return self._lib.kh_generation(self._h)
 
     def train(self, inputs: np.ndarray, obs_p: np.ndarray, obs_v: np.ndarray, *, mlr: int = 5, epochs: int = 8,
-              batchsize: int = 8):
+              batchsize: int = 8, detect_anomaly: bool = False):
         """NN::train (nn.cpp:224-377) on the device; option names and defaults of nn.cpp:236-238.
-        Returns (average loss of the first epoch, of the last epoch); the generation goes up by one."""
+        Returns (average loss of the first epoch, of the last epoch); the generation goes up by one.
+        detect_anomaly (nn.cpp:231-232,329-344): every batch's input and the forward's two outputs are checked for NaN,
+        and the call fails with the reference's messages."""
         x = np.ascontiguousarray(inputs, dtype=np.float32)
         p = np.ascontiguousarray(obs_p, dtype=np.float32)
         v = np.ascontiguousarray(obs_v, dtype=np.float32)
         n = x.shape[0]
         assert p.shape == (n, PSIZE) and v.shape == (n,)
-        cfg = L.TrainConfig(mlr / 1000.0, epochs, batchsize)
+        cfg = L.TrainConfig(mlr / 1000.0, epochs, batchsize, 1 if detect_anomaly else 0)
         first, last = C.c_float(), C.c_float()
         _chk(self._lib.kh_train(self._h, x.ctypes.data_as(C.c_void_p), p.ctypes.data_as(C.c_void_p),
                                 v.ctypes.data_as(C.c_void_p), n, C.byref(cfg), C.byref(first), C.byref(last)))
