@@ -87,6 +87,13 @@ typedef struct ks_record {
 
 typedef struct ks_pool ks_pool;
 int  ks_pool_create(kh_engine* engine, const ks_pool_config* cfg, ks_pool** out);
+/* One process, one pool, SEVERAL engines — one evaluator per GPU of the node (kh_config.device), the reference's own shape
+ * taken to N GPUs: its inference threads share one model and one replay ring in one process (selfplay.cpp:21-35,96-109,
+ * replaybuffer.h:36-56).  Worker t feeds engines[t % n] (threads >= n), finished games of every worker land in the pool's
+ * one ring (ks_pool_drain_records), ks_pool_publish_weights installs a new generation on every engine (selfplay.cpp:
+ * 282-283).  No data-path collective: leaf evaluations are independent. */
+int  ks_pool_create_multi(kh_engine* const* engines, int n_engines, const ks_pool_config* cfg, ks_pool** out);
+int  ks_pool_publish_weights(ks_pool* p, const float* blob, size_t nfloats, int generation);
 /* play until at least min_evals leaf evaluations were made or max_seconds passed; cumulative stats */
 int  ks_pool_run(ks_pool* p, int64_t min_evals, double max_seconds, ks_pool_stats* stats);
 int64_t ks_pool_drain_records(ks_pool* p, ks_record* out, int64_t cap);

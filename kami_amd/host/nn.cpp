@@ -87,11 +87,13 @@ static std::map<const NN*, std::vector<float>> g_store;
 
 void NN::create(int dtype)
 {
+    this->dtype = dtype;
     kh_config cfg;
     std::memset(&cfg, 0, sizeof cfg);
     cfg.width = width; cfg.height = height; cfg.features = features; cfg.psize = psize;
     cfg.filters = filters; cfg.residuals = residuals;
-    cfg.dtype = dtype; cfg.value_mode = KH_VALUE_REFERENCE_FLAT; cfg.device = device_from_options();
+    cfg.dtype = dtype; cfg.value_mode = KH_VALUE_REFERENCE_FLAT;
+    cfg.device = device.index >= 0 ? device.index : device_from_options();      // (a replica names its device itself)
     device.index = cfg.device;
     int rc = kh_create(&cfg, &eng);
     if (rc) raise(rc);
@@ -108,6 +110,7 @@ void NN::load_blob(const float* blob, size_t n, int generation)
 NN::NN(int width, int height, int features, int psize, bool force_cpu) :
     width(width), height(height), features(features), psize(psize)
 {
+    device.index = -1;
     if (force_cpu)
         throw std::runtime_error("kami::NN(force_cpu): the MI355X engine has no CPU path");
     filters = options::getInt("filters", 256);          // nn.cpp:42
@@ -131,12 +134,34 @@ NN::NN(int width, int height, int features, int psize, bool force_cpu) :
 
 NN::NN(NN* other) :
     width(other->width), height(other->height), features(other->features), psize(other->psize),
-    filters(other->filters), residuals(other->residuals), device(other->device)
+    filters(other->filters), residuals(other->residuals), device(other->device), dtype(other->dtype)
 {
     int rc = kh_clone(other->eng, &eng);                // nn.cpp:130-153
     if (rc) raise(rc);
     std::lock_guard<std::mutex> lk(g_store_mu);
     g_store[this] = g_store[other];
+}
+
+// One evaluator per GPU: the same network on device `device_index` (modulo the visible devices, so that two
+// replicas on one GPU can rehearse the multi-GPU control flow), with other's weights and generation.
+NN::NN(NN* other, int device_index) :
+    width(other->width), height(other->height), features(other->features), psize(other->psize),
+    filters(other->filters), residuals(other->residuals)
+{
+    const int n = kh_device_count();
+    device.index = n > 0 ? ((device_index % n) + n) % n : 0;
+    create(other->dtype);
+    sync_from(other);
+}
+
+void NN::sync_from(NN* other)
+{
+    std::vector<float> blob;
+    {
+        std::lock_guard<std::mutex> lk(g_store_mu);
+        blob = g_store[other];
+    }
+    load_blob(blob.data(), blob.size(), other->get_generation());
 }
 
 NN::~NN()

@@ -40,6 +40,7 @@ class NN {
         int width, height, features, psize;
         int filters, residuals;
         torch::Device device;
+        int dtype = 0;          // KH_F32 / KH_BF16 / KH_F16 of this engine
 
         void create(int dtype);
         void load_blob(const float* blob, size_t n, int generation);
@@ -66,8 +67,10 @@ class NN {
 
         NN* clone();
 
-        // engine extras (not in the reference): compact ingest, raw handle
+        // engine extras (not in the reference): compact ingest, raw handle, one evaluator per GPU
         kh_engine* handle() { return eng; }
+        NN(NN* other, int device_index);    // a replica of `other` on another GPU of the node (same weights, same generation)
+        void sync_from(NN* other);          // install other's current weights and generation (the weight publish after training)
 };
 
 }  // namespace kami

@@ -166,7 +166,7 @@ int ks_mcts_synthetic(int nodes, int nmoves, int leaves, const int32_t* picks, i
 // Self-play pool: Selfplay::inference_main (selfplay.cpp:58-213) with heap trees, several leaves per
 // tree and batch, compact observations in, legal priors out.
 struct ks_pool {
-    kh_engine* engine;
+    std::vector<kh_engine*> engines;    // one evaluator per GPU (ks_pool_create_multi); worker t feeds engines[t % n]
     ks_pool_config cfg;
     struct Game {
         std::unique_ptr<MCTS> tree;
@@ -302,7 +302,7 @@ struct LeafSet {
     }
 };
 
-void worker(ks_pool* p, int g0, int g1, int64_t target_evals, double deadline_s, std::chrono::steady_clock::time_point t0)
+void worker(ks_pool* p, kh_engine* engine, int g0, int g1, int64_t target_evals, double deadline_s, std::chrono::steady_clock::time_point t0)
 {
     const int L = p->cfg.leaves_per_tree > 0 ? p->cfg.leaves_per_tree : 1;
     // pipeline: the worker's trees in two (or more) sets, each set one submission to the engine's queue — while one set is
@@ -323,7 +323,7 @@ void worker(ks_pool* p, int g0, int g1, int64_t target_evals, double deadline_s,
         return p->evals.load() >= target_evals || std::chrono::duration<double>(now() - t0).count() > deadline_s;
     };
     auto finish = [&](LeafSet& s) {                      // wait for a submitted set and expand it
-        const int rc = kh_wait(p->engine, s.ticket);
+        const int rc = kh_wait(engine, s.ticket);
         s.in_flight = false;
         p->engine_ns += std::chrono::duration_cast<std::chrono::nanoseconds>(now() - s.t_submit).count();
         if (rc != KH_OK) throw std::runtime_error(std::string("kh_encode_infer_legal: ") + kh_last_error());
@@ -336,7 +336,7 @@ void worker(ks_pool* p, int g0, int g1, int64_t target_evals, double deadline_s,
                 const int nb = s.build(p, L);
                 if (nb == 0) continue;
                 const auto e0 = now();
-                const int rc = kh_encode_infer_legal(p->engine, s.boards.data(), nb, s.offsets.data(), s.actions.data(), s.priors.data(), s.values.data());
+                const int rc = kh_encode_infer_legal(engine, s.boards.data(), nb, s.offsets.data(), s.actions.data(), s.priors.data(), s.values.data());
                 p->engine_ns += std::chrono::duration_cast<std::chrono::nanoseconds>(now() - e0).count();
                 if (rc != KH_OK) throw std::runtime_error(std::string("kh_encode_infer_legal: ") + kh_last_error());
                 s.expand(p);
@@ -349,7 +349,7 @@ void worker(ks_pool* p, int g0, int g1, int64_t target_evals, double deadline_s,
                 const int nb = s.build(p, L);
                 if (nb == 0) continue;
                 s.t_submit = now();
-                const int rc = kh_submit_encode_infer_legal(p->engine, s.boards.data(), nb, s.offsets.data(), s.actions.data(), s.priors.data(),
+                const int rc = kh_submit_encode_infer_legal(engine, s.boards.data(), nb, s.offsets.data(), s.actions.data(), s.priors.data(),
                                                             s.values.data(), &s.ticket);
                 if (rc != KH_OK) throw std::runtime_error(std::string("kh_encode_infer_legal: ") + kh_last_error());
                 s.in_flight = true;
@@ -360,7 +360,7 @@ void worker(ks_pool* p, int g0, int g1, int64_t target_evals, double deadline_s,
     } catch (std::exception& e) {
         // a failed engine call must not leave virtual visits or tickets behind: the pool can be run again
         for (auto& s : sets) {
-            if (s.in_flight) { (void)kh_wait(p->engine, s.ticket); s.in_flight = false; }
+            if (s.in_flight) { (void)kh_wait(engine, s.ticket); s.in_flight = false; }
             s.release(p);
         }
         std::lock_guard<std::mutex> lk(p->err_mutex);
@@ -372,10 +372,18 @@ void worker(ks_pool* p, int g0, int g1, int64_t target_evals, double deadline_s,
 
 int ks_pool_create(kh_engine* engine, const ks_pool_config* cfg, ks_pool** out)
 {
-    if (!engine || !cfg || !out) return fail("null argument");
+    return ks_pool_create_multi(&engine, 1, cfg, out);
+}
+
+int ks_pool_create_multi(kh_engine* const* engines, int n_engines, const ks_pool_config* cfg, ks_pool** out)
+{
+    if (!engines || n_engines < 1 || !cfg || !out) return fail("null argument");
+    for (int i = 0; i < n_engines; ++i)
+        if (!engines[i]) return fail("null engine");
     if (cfg->games < 1 || cfg->threads < 1 || cfg->nodes < 2) return fail("games >= 1, threads >= 1, nodes >= 2 required");
+    if (n_engines > std::min(cfg->threads, cfg->games)) return fail("%d engines but only %d workers: every engine needs a worker of its own", n_engines, std::min(cfg->threads, cfg->games));
     ks_pool* p = new ks_pool();
-    p->engine = engine;
+    p->engines.assign(engines, engines + n_engines);
     p->cfg = *cfg;
     if (cfg->pipeline) {
         // The queue's limits (include/kami_hip.h: a submission holds at most 512 positions, an engine at most
@@ -422,31 +430,36 @@ int ks_pool_run(ks_pool* p, int64_t min_evals, double max_seconds, ks_pool_stats
     // later synchronous small call must not wait out this pool's quiet period, and ks_pool_destroy never touches the
     // engine: it may be gone by then).
     struct PipeGuard {
-        kh_engine* e = nullptr;
+        std::vector<kh_engine*> es;
         ~PipeGuard()
         {
-            if (!e) return;
-            (void)kh_set_coalesce_callers(e, 0);
-            (void)kh_set_coalesce(e, 0, 0);
+            for (kh_engine* e : es) {
+                (void)kh_set_coalesce_callers(e, 0);
+                (void)kh_set_coalesce(e, 0, 0);
+            }
             std::lock_guard<std::mutex> lk(g_pipe_mu);
-            g_pipe_engines.erase(e);
+            for (kh_engine* e : es) g_pipe_engines.erase(e);
         }
     } guard;
+    const int NE = (int)p->engines.size();
     if (p->cfg.pipeline) {
         {
             std::lock_guard<std::mutex> lk(g_pipe_mu);
-            if (!g_pipe_engines.insert(p->engine).second) return fail("another pipelined pool is running on this engine (the queue's merge settings are per engine)");
+            for (kh_engine* e : p->engines)
+                if (g_pipe_engines.count(e)) return fail("another pipelined pool is running on one of these engines (the queue's merge settings are per engine)");
+            for (kh_engine* e : p->engines) { g_pipe_engines.insert(e); guard.es.push_back(e); }
         }
-        guard.e = p->engine;
-        if (kh_set_coalesce(p->engine, p->cfg.coalesce_target, p->cfg.coalesce_wait_us) != KH_OK) return fail("%s", kh_last_error());
-        // every worker submits one set per round: a launch that holds a submission of each is a whole round
-        if (p->cfg.coalesce_target > 0) (void)kh_set_coalesce_callers(p->engine, T);
+        for (int i = 0; i < NE; ++i) {
+            if (kh_set_coalesce(p->engines[i], p->cfg.coalesce_target, p->cfg.coalesce_wait_us) != KH_OK) return fail("%s", kh_last_error());
+            // every worker of an engine submits one set per round: a launch that holds a submission of each is a whole round
+            if (p->cfg.coalesce_target > 0) (void)kh_set_coalesce_callers(p->engines[i], (T - i + NE - 1) / NE);
+        }
     }
     const int64_t target = p->evals.load() + min_evals;
     std::vector<std::thread> th;
     for (int t = 0; t < T; ++t) {
         const int g0 = (int)((int64_t)p->cfg.games * t / T), g1 = (int)((int64_t)p->cfg.games * (t + 1) / T);
-        th.emplace_back(worker, p, g0, g1, target, max_seconds, t0);
+        th.emplace_back(worker, p, p->engines[(size_t)t % p->engines.size()], g0, g1, target, max_seconds, t0);
     }
     for (auto& x : th) x.join();
     p->seconds += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
@@ -471,6 +484,16 @@ int64_t ks_pool_drain_records(ks_pool* p, ks_record* out, int64_t cap)
     if (n > 0 && out) memcpy(out, p->records.data(), (size_t)n * sizeof(ks_record));
     p->records.erase(p->records.begin(), p->records.begin() + n);
     return n;
+}
+
+int ks_pool_publish_weights(ks_pool* p, const float* blob, size_t nfloats, int generation)
+{
+    if (!p || !blob) return fail("null argument");
+    // selfplay.cpp:282-283 (model->read(path) after an accepted candidate) for every evaluator of the pool: each engine
+    // swaps atomically, evaluations in flight finish on the weights they started with
+    for (kh_engine* e : p->engines)
+        if (kh_load_weights(e, blob, nfloats, generation) != KH_OK) return fail("%s", kh_last_error());
+    return 0;
 }
 
 void ks_pool_destroy(ks_pool* p)

@@ -13,6 +13,7 @@
 #include <ctime>
 #include <iostream>
 #include <list>
+#include <memory>
 #include <stdexcept>
 #include <thread>
 #include <vector>
@@ -88,6 +89,12 @@ void check(int rc)
 struct Selfplay::Impl {
     Selfplay* self;
     NN* model;
+    // Option "engine_devices" = N > 1: one evaluator per GPU in this one process — the reference's shape (N inference
+    // threads sharing one ring, selfplay.cpp:21-35,96-109) taken across the node.  engines[0] is the caller's model (the
+    // trainer's and the gate's), engines[d] a replica on device d; inference thread i feeds engines[i % N]; an accepted
+    // candidate is published to every replica (selfplay.cpp:282-283).
+    std::vector<std::unique_ptr<NN>> replicas;
+    std::vector<NN*> engines;
     ReplayBuffer replay;
     int ibatch, nodes;
     std::vector<std::thread> inference, training;
@@ -97,11 +104,20 @@ struct Selfplay::Impl {
 
     Impl(Selfplay* s, NN* m)             // selfplay.cpp:13-19
         : self(s), model(m), replay(OBSIZE, PSIZE, options::getInt("replaybuffer_size", 512)),
-          ibatch(options::getInt("selfplay_batch", 16)), nodes(options::getInt("selfplay_nodes", 512)) {}
+          ibatch(options::getInt("selfplay_batch", 16)), nodes(options::getInt("selfplay_nodes", 512))
+    {
+        engines.push_back(model);
+        const int ndev = std::max(1, options::getInt("engine_devices", 1));
+        for (int d = 1; d < ndev; ++d) {
+            replicas.emplace_back(new NN(model, model->get_device().index + d));
+            engines.push_back(replicas.back().get());
+        }
+        if (ndev > 1) std::cout << "Selfplay: " << ndev << " evaluators (engine_devices), inference thread i on engine i % " << ndev << std::endl;
+    }
 
     bool running() { return self->status.code() == RUNNING; }
 
-    void finish_game(Game& g, float value, const PlayOptions& po, std::vector<float>& planes)
+    void finish_game(NN* mine, Game& g, float value, const PlayOptions& po, std::vector<float>& planes)
     {
         Env& env = g.tree->get_env();
         if (wants_pgn.exchange(false)) ret_pgn = movetext(g, env, value);
@@ -110,7 +126,7 @@ struct Selfplay::Impl {
         std::vector<kh_board> boards((size_t)n);
         for (int k = 0; k < n; ++k) boards[k] = g.trajectory[k].board;
         planes.resize((size_t)n * OBSIZE);
-        check(kh_encode(model->handle(), boards.data(), n, planes.data()));
+        check(kh_encode(mine->handle(), boards.data(), n, planes.data()));
         for (int k = 0; k < n; ++k) {
             const Game::Step& st = g.trajectory[k];
             replay.add(planes.data() + (size_t)k * OBSIZE, st.visits.data(), value == 0.0f ? po.draw_value : st.pov * value);
@@ -120,13 +136,14 @@ struct Selfplay::Impl {
     void inference_main(int id)          // selfplay.cpp:58-213
     {
         std::cout << "Starting inference thread: " << id << std::endl;
+        NN* const mine = engines[(size_t)id % engines.size()];
         const PlayOptions po;
         MCTSConfig cfg = search_options();
         std::vector<Game> games((size_t)ibatch);
         for (int i = 0; i < ibatch; ++i) {
             cfg.seed = (unsigned)time(nullptr) * 2654435761u + (unsigned)(id * 100003 + i);
             games[i].tree.reset(new MCTS(cfg));
-            games[i].generation = model->get_generation();
+            games[i].generation = mine->get_generation();
         }
         std::vector<kh_board> boards;
         std::vector<int32_t> offsets, actions;
@@ -141,9 +158,9 @@ struct Selfplay::Impl {
                 for (Game& g : games) {
                     MCTS& tree = *g.tree;
                     for (;;) {
-                        if (po.flush_old_trees && g.generation < model->get_generation()) {      // selfplay.cpp:115-127
+                        if (po.flush_old_trees && g.generation < mine->get_generation()) {       // selfplay.cpp:115-127
                             open_steps -= g.drop();
-                            g.generation = model->get_generation();
+                            g.generation = mine->get_generation();
                         }
                         bool leaf = false;
                         while (tree.n() < nodes && !(leaf = tree.select_leaf(&g.leaf))) {}        // selfplay.cpp:130
@@ -162,7 +179,7 @@ struct Selfplay::Impl {
                         tree.push(picked);
                         float value;
                         if (env.terminal(&value)) {                                               // selfplay.cpp:163-189
-                            finish_game(g, value, po, planes);
+                            finish_game(mine, g, value, po, planes);
                             open_steps -= g.drop();
                         }
                     }
@@ -174,7 +191,7 @@ struct Selfplay::Impl {
                 // the batch: one leaf of every tree (selfplay.cpp:196-200), as records + legal actions
                 priors.resize(actions.size());
                 values.resize(boards.size());
-                check(kh_encode_infer_legal(model->handle(), boards.data(), (int)boards.size(), offsets.data(), actions.data(),
+                check(kh_encode_infer_legal(mine->handle(), boards.data(), (int)boards.size(), offsets.data(), actions.data(),
                                             priors.data(), values.data()));
                 for (size_t j = 0; j < owner.size(); ++j) owner[j]->tree->expand_leaf(owner[j]->leaf, priors.data() + offsets[j], values[j]);
                 *partials = open_steps;                                                           // selfplay.cpp:203-205
@@ -229,6 +246,7 @@ struct Selfplay::Impl {
             }
             candidate.write(modelpath);                                                    // selfplay.cpp:282-283
             model->read(modelpath);
+            for (auto& r : replicas) r->sync_from(model);                                  // every evaluator serves the new generation
             std::cout << "TRAIN " << id << ": candidate accepted: using new generation " << model->get_generation() << std::endl;
             if (options::getInt("flush_old_rpb", 1)) replay.clear();
             from = replay.count();

@@ -5,7 +5,7 @@ F = 30.  `add` / `select_batch` / `count` / `size` / `clear` keep the reference'
 not yet written — they read as zeros here where the reference reads uninitialised memory).
 
 `gather` is new (the reference is single-process): every rank contributes the records it added
-since the last gather; they are merged into the root's ring in rank-major order (the reference's
+since the last gather; they are gathered to the root and merged into its ring in rank-major order (the reference's
 insertion order is thread-racy, so any fixed order is acceptable — SURVEY §8e).  It runs over
 torch.distributed: RCCL/xGMI with device tensors on GPUs, gloo on CPU.  Never on the timed
 evaluation path.
@@ -79,8 +79,10 @@ class ReplayBuffer:
             return 0
         pad = torch.zeros((nmax, width), dtype=torch.float32, device=device)
         pad[:mine.shape[0]] = torch.from_numpy(mine).to(device)
-        outs = [torch.empty_like(pad) for _ in range(world)]
-        dist.all_gather(outs, pad)      # small, latency-bound payloads: one collective, fixed shapes
+        # gather TO THE ROOT (only the trainer rank consumes the records: an all-gather would move world x the bytes,
+        # which matters at 26 KB per dense row); fixed shapes, one collective
+        outs = [torch.empty_like(pad) for _ in range(world)] if rank == root else None
+        dist.gather(pad, gather_list=outs, dst=root)
         inserted = 0
         if rank == root:
             for r in range(world):
@@ -98,8 +100,8 @@ def gather_compact(dist, payload: bytes, record_bytes: int, root: int = 0, devic
     """Merge fixed-size compact records (ks_record, 664 bytes: board + sparse visit distribution + value —
     include/kami_search.h) over the ranks: 40x less traffic than the dense 26 372-byte rows `gather` moves.
     Every rank passes its own records; returns the list of every rank's payload (rank-major) on `root`, and
-    [] elsewhere.  One size all-reduce + one all-gather of uint8 (RCCL over xGMI with device tensors, gloo
-    on CPU)."""
+    [] elsewhere.  One size all-reduce + one gather of uint8 to the root (RCCL over xGMI with device tensors: the
+    root's seven direct links carry one rank's payload each; gloo on CPU)."""
     import torch
     if dist is None:
         return [payload]
@@ -116,8 +118,8 @@ def gather_compact(dist, payload: bytes, record_bytes: int, root: int = 0, devic
     pad = torch.zeros(nmax, dtype=torch.uint8, device=device)
     if payload:
         pad[:len(payload)] = torch.frombuffer(bytearray(payload), dtype=torch.uint8).to(device)
-    outs = [torch.empty_like(pad) for _ in range(world)]
-    dist.all_gather(outs, pad)
+    outs = [torch.empty_like(pad) for _ in range(world)] if rank == root else None
+    dist.gather(pad, gather_list=outs, dst=root)
     if rank != root:
         return []
     return [outs[r][:int(counts[r].item())].cpu().numpy().tobytes() for r in range(world)]

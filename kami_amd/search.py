@@ -55,6 +55,8 @@ SYMBOLS = {
     "ks_env_record": (None, [C.c_void_p, C.POINTER(Board)]),
     "ks_mcts_synthetic": (C.c_int, [C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int32), C.c_int, C.c_char_p, C.c_int]),
     "ks_pool_create": (C.c_int, [C.c_void_p, C.POINTER(PoolConfig), C.POINTER(C.c_void_p)]),
+    "ks_pool_create_multi": (C.c_int, [C.POINTER(C.c_void_p), C.c_int, C.POINTER(PoolConfig), C.POINTER(C.c_void_p)]),
+    "ks_pool_publish_weights": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]),
     "ks_pool_run": (C.c_int, [C.c_void_p, C.c_int64, C.c_double, C.POINTER(PoolStats)]),
     "ks_pool_drain_records": (C.c_int64, [C.c_void_p, C.POINTER(Record), C.c_int64]),
     "ks_pool_destroy": (None, [C.c_void_p]),
@@ -161,7 +163,7 @@ _POOLS = weakref.WeakSet()      # live pools: closed before their engines (kami_
 def close_pools_of(nn=None):
     """Close every live pool (of engine `nn`, or of any engine): a pool must not outlive the engine it feeds."""
     for pool in list(_POOLS):
-        if nn is None or pool.nn is nn:
+        if nn is None or any(e is nn for e in pool.engines):
             pool.close()
 
 
@@ -172,11 +174,13 @@ class Pool:
                  alpha=(1.0, 1.0, 1.0), alpha_cutoff=1, draw_value_pct=50, seed=1, pipeline=False, coalesce_target=0,
                  coalesce_wait_us=0):
         self.lib = load()
-        self.nn = nn                      # keep the engine alive
+        self.engines = list(nn) if isinstance(nn, (list, tuple)) else [nn]      # one evaluator per GPU; kept alive
+        self.nn = self.engines[0]
         cfg = PoolConfig(games, threads, nodes, leaves_per_tree, cpuct, noise_weight, alpha[0], alpha[1], alpha[2],
                          alpha_cutoff, draw_value_pct, seed, int(pipeline), coalesce_target, coalesce_wait_us)   # pipeline: False / True (two sets) / 2..4 sets
         self.h = C.c_void_p()
-        if self.lib.ks_pool_create(nn.handle, C.byref(cfg), C.byref(self.h)):
+        handles = (C.c_void_p * len(self.engines))(*[e.handle for e in self.engines])
+        if self.lib.ks_pool_create_multi(handles, len(self.engines), C.byref(cfg), C.byref(self.h)):
             self.h = None
             raise RuntimeError(self.lib.ks_last_error().decode())
         _POOLS.add(self)
@@ -188,6 +192,15 @@ class Pool:
         if self.lib.ks_pool_run(self.h, int(min_evals), float(max_seconds), C.byref(st)):
             raise RuntimeError(self.lib.ks_last_error().decode())
         return st
+
+    def publish_weights(self, blob, generation: int):
+        """A new generation on every engine of the pool (selfplay.cpp:282-283)."""
+        import numpy as np
+        blob = np.ascontiguousarray(blob, dtype=np.float32)
+        if self.lib.ks_pool_publish_weights(self.h, blob.ctypes.data_as(C.c_void_p), blob.size, int(generation)):
+            raise RuntimeError(self.lib.ks_last_error().decode())
+        for e in self.engines:
+            e._blob = blob
 
     def drain(self, cap=1 << 16):
         buf = (Record * cap)()

@@ -839,6 +839,73 @@ def test_reference_kami_program_full_cycle_on_the_cpp_mirror(tmp_path, program):
         assert "[White \"KAMI generation" in out and (" 1-0 {" in out or " 0-1 {" in out or " 1/2-1/2 {" in out)
 
 
+def test_kami_native_two_evaluators_in_one_process(tmp_path):
+    """One process, TWO engines (option engine_devices = 2; on a one-GPU box both land on device 0, on a node one per
+    GPU): inference thread i feeds engine i % 2, finished games of both go into the one replay ring, an accepted candidate
+    is published to both engines (selfplay.cpp:21-35,96-109,176-184,282-283).  The unmodified kami.cpp plays, trains,
+    gates and swaps a generation on it."""
+    import os, subprocess, time, threading
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(root, "oracle", "_ref", "dropin", "kami_native")
+    if not os.path.exists(exe):
+        pytest.skip("drop-in binaries not built (needs the reference tree at build time)")
+    opts = dict(filters=16, residuals=1, selfplay_batch=16, selfplay_nodes=16, inference_threads=4, training_threads=1,
+                replaybuffer_size=128, rpb_train_pct=40, training_sample_pct=60, training_epochs=2, training_batchsize=8,
+                training_mlr=5, evaluate_batch=8, evaluate_games=8, evaluate_nodes=8, evaluate_target_pct=0,
+                model_path=str(tmp_path / "model.bin"), engine_dtype="bf16", engine_devices=2)
+    (tmp_path / "options.yml").write_text("".join(f"{k}: {v}\n" for k, v in opts.items()))
+    proc = subprocess.Popen([exe], cwd=tmp_path, stdin=subprocess.PIPE, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    lines = []
+    t = threading.Thread(target=lambda: lines.extend(iter(proc.stdout.readline, "")), daemon=True)
+    t.start()
+    deadline = time.time() + 150
+    while time.time() < deadline and proc.poll() is None and not any("candidate accepted" in l for l in lines):
+        time.sleep(1.0)
+    time.sleep(3.0)                       # a few rounds on the new generation
+    try:
+        proc.stdin.write("status\nquit\n"); proc.stdin.flush()
+        proc.wait(timeout=60)
+    except Exception:
+        proc.kill()
+    out = "".join(lines)
+    assert "Selfplay: 2 evaluators" in out, out[-3000:]
+    assert "kami::NN: MI355X engine" in out            # the mirror says which arithmetic it computes in
+    assert "candidate accepted: using new generation 1" in out, out[-3000:]
+    assert "INFER" not in out, out[-3000:]            # no inference thread died
+    for i in range(4):
+        assert f"Starting inference thread: {i}" in out and f"Terminating inference thread: {i}" in out
+
+
+def test_pool_with_two_engines_and_weight_publish():
+    """ks_pool_create_multi: one pool, two engines (both on device 0 here), workers sharded over them, ONE record ring;
+    ks_pool_publish_weights puts a new generation on both; pipelined and blocking schedules."""
+    from kami_amd import search as S
+    F, C, R = 30, 64, 2
+    blob0, blob1 = W.random_weights(F, C, R, seed=1, peaky=5.0), W.random_weights(F, C, R, seed=2, peaky=5.0)
+    engines = [NN(8, 8, F, 4672, filters=C, residuals=R, dtype="bf16", value_mode=L.KH_VALUE_PER_SAMPLE0) for _ in range(2)]
+    for e in engines:
+        e.load_weights(blob0, 3)
+    for pipeline in (0, 1):
+        pool = S.Pool(engines, games=96, threads=4, nodes=24, leaves_per_tree=2, seed=5, pipeline=pipeline, coalesce_target=48, coalesce_wait_us=100)
+        st = pool.run(min_evals=4000, max_seconds=20.0)
+        assert st.evals >= 4000 and st.moves > 0
+        pool.publish_weights(blob1, 4)
+        assert [e.get_generation() for e in engines] == [4, 4]
+        st2 = pool.run(min_evals=2000, max_seconds=20.0)
+        assert st2.evals >= st.evals + 2000
+        recs = pool.drain()
+        assert st2.games_finished == 0 or len(recs) > 0
+        pool.close()
+        for e in engines:
+            e.load_weights(blob0, 3)
+    # both engines really evaluated: each one's queue / call counters moved (the pipelined run goes through the queues)
+    assert all(e.coalesce_stats()[0] > 0 for e in engines)
+    with pytest.raises(RuntimeError, match="every engine needs a worker"):
+        S.Pool(engines, games=8, threads=1, nodes=8)
+    for e in engines:
+        e.close()
+
+
 @pytest.mark.parametrize("program", ["kami", "kami_native"])
 def test_configs0_literal_one_game_64_sims(tmp_path, program):
     """BASELINE configs[0] literally — 1 self-play game, 64 MCTS sims per move (test/selfplay.cpp's path: one inference
