@@ -387,6 +387,7 @@ def main():
     ap.add_argument("--repeats", type=int, default=60, help="separately timed repeats for p10 / median / p90")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-variants", action="store_true", help="skip the variants / end_to_end legs (N = 1 only anyway)")
+    ap.add_argument("--no-legs", action="store_true", help="skip value_f32 / encode / configs0 too: the headline kernel alone (profiler passes)")
     a = ap.parse_args()
 
     import numpy as np
@@ -489,7 +490,7 @@ def main():
             "distribution": {"unit": "leaf-evals/s per GPU (this rank)", "repeats": len(rates), "steps_per_repeat": per,
                              "p10": round(pct(0.10), 1), "median": round(pct(0.50), 1), "p90": round(pct(0.90), 1)},
         }
-        if world == 1:
+        if world == 1 and not a.no_legs:
             del leg
             torch.cuda.empty_cache()
             f32 = DeviceLeg(torch, lib, NN, W, "f32", F, Cc, R, B, 7, dev_index)
@@ -501,7 +502,7 @@ def main():
             torch.cuda.empty_cache()
             out["encode"] = encode_leg(torch, lib, NN, L, dev_index)
             out["configs0"] = configs0_leg(NN, W, L, dev_index)
-        if world == 1 and not a.no_variants:
+        if world == 1 and not a.no_variants and not a.no_legs:
             out["variants"] = variant_legs(torch, lib, NN, W, L, dev_index, a.prewarm)
             out["end_to_end"] = end_to_end_legs(NN, W, L, dev_index)
         if world == 1 and not a.no_cpu_baseline:

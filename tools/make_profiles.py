@@ -81,18 +81,18 @@ rows = stats_rows("kt")
 write_stats(rows, f"{tag}_kernel_stats.csv")
 ctr = {}
 for d in ("pmc_fetch", "pmc_write", "pmc_sq"):
-    ctr.update(counters(d, "tower8_kernel") or counters(d, "tower_kernel"))
+    ctr.update(counters(d, "tower8_kernelIDF16bLi8ELb0E") or counters(d, "tower8_kernel") or counters(d, "tower_kernel"))
 summary = {
     "round": rnd, "kernel_source_sha16": sha,
-    "command": "rocprofv3 --kernel-trace --stats --output-format csv -- python3 bench.py --no-cpu-baseline --no-variants   (default --steps 2000 --warmup 200 --prewarm 0.3)",
-    "pmc_commands": ["rocprofv3 --pmc FETCH_SIZE --output-format csv -- python3 bench.py --steps 20 --warmup 5 --prewarm 0 --repeats 1 --no-cpu-baseline --no-variants",
+    "command": "rocprofv3 --kernel-trace --stats --output-format csv -- python3 bench.py --no-cpu-baseline --no-variants --no-legs   (default --steps 2000 --warmup 200 --prewarm 0.3)",
+    "pmc_commands": ["rocprofv3 --pmc FETCH_SIZE --output-format csv -- python3 bench.py --steps 20 --warmup 5 --prewarm 0 --repeats 1 --no-cpu-baseline --no-variants --no-legs",
                      "rocprofv3 --pmc WRITE_SIZE ... (same)", "rocprofv3 --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_INST_LDS SQ_WAIT_ANY SQ_ACTIVE_INST_LDS ... (same)"],
     "workload": cfg["workload"],
     "workload_key": {"features": F, "filters": C, "residuals": R, "batch": Bb, "dtype": bench["dtype"]},
     "bench_line": {k: bench[k] for k in ("value", "ms_per_step", "roofline", "distribution") if k in bench},
     "counters": ctr,
 }
-tower = [r for r in rows if "tower8_kernel" in r["Name"] or "tower_kernel" in r["Name"]]
+tower = [r for r in rows if "tower8_kernelIDF16bLi8ELb0E" in r["Name"]] or [r for r in rows if "tower8_kernel" in r["Name"] or "tower_kernel" in r["Name"]]
 if tower:
     t = tower[0]
     summary["tower_kernel"] = {"name": t["Name"], "calls": int(t["Calls"]), "avg_ns": float(t["AverageNs"]), "min_ns": float(t["MinNs"]), "max_ns": float(t["MaxNs"])}

@@ -7,7 +7,7 @@ set -o pipefail
 O=gpurun_out/prof
 rm -rf $O; mkdir -p $O
 export TMPDIR=/tmp
-B="--no-cpu-baseline --no-variants"
+B="--no-cpu-baseline --no-variants --no-legs"
 SQ="SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_INST_LDS SQ_WAIT_ANY SQ_ACTIVE_INST_LDS"
 timeout -k 10 300 python bench.py > $O/bench_default.json 2> $O/bench_default.err || { tail $O/bench_default.err; exit 1; }
 echo "bench done"
