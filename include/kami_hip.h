@@ -216,6 +216,11 @@ int  kh_submit_encode_infer_legal(kh_engine* e, const kh_board* boards, int batc
                                   const int32_t* action_offsets, const int32_t* actions,
                                   float* priors, float* value, int64_t* ticket);
 int  kh_wait(kh_engine* e, int64_t ticket);
+/* kh_wait without the wait: *done = 1 and the ticket is consumed exactly as by kh_wait (return value = its status) when
+ * the results are in the caller's buffers; *done = 0 and KH_OK when the launch is still on its way (the ticket stays
+ * valid).  For a caller with several tickets in flight that wants whichever finishes first (the self-play pool's
+ * workers: launches do not complete in submission order once several are on the device). */
+int  kh_try_wait(kh_engine* e, int64_t ticket, int* done);
 /* Launch policy of the queue.  target_batch 0 (default): whatever has accumulated goes as soon as a launch lane is
  * free.  target_batch > 0: a batch waits until it holds that many positions, but at most max_wait_us after its first
  * submission and no longer than max_wait_us / 8 after its latest one (the burst has ended) — for callers that know how

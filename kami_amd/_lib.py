@@ -60,6 +60,7 @@ SYMBOLS = {
     "kh_submit_infer": (C.c_int, [_P, _P, C.c_int, _P, _P, C.POINTER(C.c_int64)]),
     "kh_submit_encode_infer_legal": (C.c_int, [_P, _P, C.c_int, _P, _P, _P, _P, C.POINTER(C.c_int64)]),
     "kh_wait": (C.c_int, [_P, C.c_int64]),
+    "kh_try_wait": (C.c_int, [_P, C.c_int64, C.POINTER(C.c_int)]),
     "kh_set_coalesce": (C.c_int, [_P, C.c_int, C.c_int]),
     "kh_set_coalesce_callers": (C.c_int, [_P, C.c_int]),
     "kh_coalesce_stats": (C.c_int, [_P, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),

@@ -118,4 +118,21 @@ void launch_gather_legal(const float* policy, const int32_t* offsets, const int3
                        flags_in, flags_out);
 }
 
+// One word into page-locked host memory when everything before it on the stream has finished: the queue's dispatcher
+// polls that word instead of hipStreamQuery (tools/completion_probe.hip: the word is there 6-8 us before the runtime's
+// own completion signal has been processed).  Stream order makes the results of the kernels before it complete; they
+// and this word are posted writes of the same device to the same host.
+__global__ void signal_kernel(unsigned* host_word, unsigned serial)
+{
+    if (threadIdx.x == 0) {
+        __threadfence_system();
+        __hip_atomic_store(host_word, serial, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+}
+
+void launch_signal(unsigned* host_word, unsigned serial, hipStream_t s)
+{
+    hipLaunchKernelGGL(signal_kernel, dim3(1), dim3(64), 0, s, host_word, serial);
+}
+
 }  // namespace kh

@@ -532,6 +532,8 @@ struct kh_engine {
     std::unique_ptr<Slot> devslot;           // scratch for the device-pointer API
     std::mutex dmu;
     Coalescer* co = nullptr;          // submit / wait queue (created on first use)
+    std::atomic<Coalescer*> co_ready{ nullptr };     // the same pointer once the lanes run: submitters skip co_mu
+    std::atomic<bool> has_weights{ false };
     std::mutex co_mu;
     std::atomic<int> small_calls{ 0 };       // synchronous small-batch calls currently inside the engine
     std::atomic<int> co_target{ 0 }, co_wait_us{ 0 }, co_callers{ 0 };
@@ -983,12 +985,34 @@ constexpr int CO_ROWS = 1024;                   // boards per coalesced launch (
 constexpr int CO_ACTS = CO_ROWS * 48;           // legal actions per coalesced launch
 constexpr int CO_SMALL_LEGAL = 512;             // a submission larger than this takes the direct path
 constexpr int CO_SMALL_PLANES = 128;
-constexpr int CO_BUFFERS = 6;
-constexpr int CO_LANES = 4;                     // at most; two run unless KAMI_CO_LANES says otherwise
+constexpr int CO_BUFFERS = 12;                  // up to max_inflight on the device, one filling, the rest waiting for their callers to fetch
+
+// The queue's lock.  Its critical sections are a few hundred nanoseconds (reserve rows, scan six batches) and a dozen
+// workers hit it within the same microsecond when a launch hands their tickets back: with std::mutex the losers sleep
+// on the futex and are woken one after the other (2-3 us each: measured as 33-37 us of "filling" per launch with 14
+// workers), so it spins.  Sleeping paths (idle lane, buffers all on the device, waiters past their spin time) go
+// through std::condition_variable_any, which takes any lock type.
+struct SpinLock {
+    std::atomic<int> held{ 0 };
+    void lock()
+    {
+        for (int k = 0;; ++k) {
+            if (!held.exchange(1, std::memory_order_acquire)) return;
+            while (held.load(std::memory_order_relaxed)) {
+                __builtin_ia32_pause();
+                if ((++k & 1023) == 0) sched_yield();       // more threads than cores: the holder may need this one
+            }
+        }
+    }
+    bool try_lock() { return !held.exchange(1, std::memory_order_acquire); }
+    void unlock() { held.store(0, std::memory_order_release); }
+};
 
 struct CoTicket {
     uint32_t serial = 0;
-    std::atomic<int> state{ 0 };                // 0 free, 1 queued, 2 done (waiters spin on it, then sleep)
+    std::atomic<int> state{ 0 };                // 0 free, 1 queued, 2 done: results in the caller's buffers (waiters spin on it, then
+                                                // sleep), 4 results in the batch's page-locked block, 5 somebody is copying them out
+    struct CoBatch* from = nullptr;             // state 4 / 5: the batch that holds this ticket's rows
     int status = KH_OK;
     std::string err;
     int kind = 0, row0 = 0, rows = 0, act0 = 0, nact = 0;
@@ -999,10 +1023,14 @@ struct CoTicket {
 };
 
 struct CoBatch {
-    int state = 0;                              // 0 free, 1 open, 2 sealed (a lane owns it)
+    int state = 0;                              // 0 free, 1 open, 2 sealed (the dispatcher owns it; after completion until the last
+                                                // ticket's rows have been copied out)
     int kind = 0;                               // 0: records + legal actions -> priors; 1: planes -> full policy rows
     int rows = 0, nact = 0;
     std::atomic<int> copying{ 0 };              // submitters that have reserved rows and are still copying them in
+    std::atomic<int> readers{ 0 };              // tickets whose rows are still in the block (state 4 / 5)
+    unsigned* done = nullptr;                   // word in pin_out that signal_kernel sets to `serial` behind the launch
+    unsigned serial = 0;
     bool full = false;
     std::chrono::steady_clock::time_point first, last;     // first / latest submission into this batch
     std::vector<CoTicket*> tickets;
@@ -1014,85 +1042,142 @@ struct CoBatch {
     int32_t *offsets = nullptr, *actions = nullptr;
     float *priors = nullptr, *values = nullptr;
     int* flags_out = nullptr;
-    Slot slot;                                  // stream + device scratch of this buffer's launches
+    Slot* lane = nullptr;                       // stream + device scratch of the launch this buffer is on (Coalescer::lanes)
+    std::shared_ptr<Weights> W;                 // the weights a launch that is on the device runs on
+    std::chrono::steady_clock::time_point t_seal, t_run, t_launched;
     std::vector<float> planes, vfull, policy;   // kind 1 / reference value copy-out: plain host staging for infer_host
 };
 
 struct Coalescer {
     kh_engine* e;
-    std::mutex mu;
-    std::condition_variable cv_lane, cv_done, cv_space;
+    SpinLock mu;
+    std::condition_variable_any cv_lane, cv_done, cv_space;
     CoTicket tickets[KH_MAX_OUTSTANDING];
     CoBatch batches[CO_BUFFERS];
-    std::thread lanes[CO_LANES];
-    int lanes_busy = 0, sleepers = 0;
-    int spin_us = 150;                          // kh_wait spins this long on its ticket before it sleeps (KAMI_WAIT_SPIN_US)
+    std::thread dispatcher;
+    // Launches on the device at once: each on a lane = a stream of its own + device scratch.  FOUR streams, created one
+    // after the other, because that is how many hardware queues the runtime spreads streams over: with a stream per
+    // merge buffer (12) launches that were "in flight together" shared a queue and ran one behind the other (engine
+    // call 80-110 us with four in flight against 38-41 with two).  KAMI_CO_INFLIGHT lowers it.
+    static constexpr int MAX_LANES = 4;
+    Slot lanes[MAX_LANES];
+    bool lane_busy[MAX_LANES] = { false, false, false, false };
+    int max_inflight = MAX_LANES;
+    int sleepers = 0;
+    int spin_us = 1000;                         // kh_wait spins this long on its ticket before it sleeps (KAMI_WAIT_SPIN_US): a
+                                                // sleeper costs the dispatcher a futex wake per launch and itself 10-50 us, and one
+                                                // slow cycle (> 150 us, round 2's value) used to tip a pool into that regime for good
     bool stop = false;
     int64_t launches = 0, rows_launched = 0;
     // KAMI_CO_TRACE=1: where a coalesced launch's time goes (printed when the engine is destroyed)
     bool trace = false;
-    double us_fill = 0, us_copywait = 0, us_run = 0, us_finish = 0;
+    double us_fill = 0, us_copywait = 0, us_launch = 0, us_run = 0, us_finish = 0;
 };
 
 // records + legal actions -> priors + one value per position, straight out of / into the batch's page-locked blocks:
-// forward kernel(s) and the gather kernel on the buffer's own stream, completion polled (hipStreamQuery) instead of a
-// blocking wait — the launch's latency is what every waiting caller pays.
-int co_run_legal_direct(kh_engine* e, CoBatch& b)
+// forward kernel(s) and the gather kernel on the buffer's own stream.  Launch only: the dispatcher polls the stream
+// (hipStreamQuery) and calls co_finish_legal when it has drained — the launch's latency is what every waiting caller pays.
+int co_launch_legal(kh_engine* e, CoBatch& b)
 {
     const int B = b.rows;
-    std::shared_ptr<Weights> W = current_weights(e);
-    if (!W) return fail(KH_ERR_NO_WEIGHTS, "kh_infer before kh_load_weights");
+    b.W = current_weights(e);                   // kept until the launch has completed
+    if (!b.W) return fail(KH_ERR_NO_WEIGHTS, "kh_infer before kh_load_weights");
+    const Weights& W = *b.W;
     int rc = set_device(e);
     if (rc) return rc;
-    Slot& s = b.slot;
-    if ((rc = slot_ensure(e, s, B, true))) return rc;
+    Slot& s = *b.lane;
+    if ((rc = slot_ensure(e, s, CO_ROWS, true))) return rc;        // sized once for the largest merged launch: no allocation (= device sync) mid-run
     hipStream_t st = s.stream;
-    if (fused_ingest(e, *W)) {
+    if (fused_ingest(e, W)) {
         // one launch: records in, legal priors + values + NaN flags out, all through the batch's page-locked blocks
         b.flags_out[0] = b.flags_out[1] = 0;
         const LegalDev lg{ b.offsets, b.actions, b.priors, b.values, b.flags_out };
-        rc = forward_tower(e, *W, s, nullptr, B, s.policy.as<float>(), s.vfull.as<float>(), nullptr, b.boards, &lg);
+        rc = forward_tower(e, W, s, nullptr, B, s.policy.as<float>(), s.vfull.as<float>(), nullptr, b.boards, &lg);
         if (rc) return rc;
     } else {
         kh::launch_encode_f32(b.boards, B, s.planes.as<float>(), st);
-        rc = forward_dispatch(e, *W, s, s.planes.as<float>(), B, s.policy.as<float>(), s.vfull.as<float>(), nullptr);
+        rc = forward_dispatch(e, W, s, s.planes.as<float>(), B, s.policy.as<float>(), s.vfull.as<float>(), nullptr);
         if (rc) return rc;
         kh::launch_gather_legal(s.policy.as<float>(), b.offsets, b.actions, b.priors, B, st, s.vfull.as<float>(), KH_VALUE_WIDTH, b.values,
                                 s.flags.as<int>(), b.flags_out);
     }
+    // (the forward kernel's LAST workgroup writing the word itself was tried: its results then have to be system-scope
+    //  stores, ~8 000 four-byte PCIe writes per launch instead of L2-combined lines — engine call 43-46 us against 38-40)
+    if (++b.serial == 0) b.serial = 1;
+    kh::launch_signal(b.done, b.serial, st);
     HIPCHK(hipGetLastError());
-    for (int k = 0;; ++k) {
-        const hipError_t q = hipStreamQuery(st);
-        if (q == hipSuccess) break;
-        if (q != hipErrorNotReady) return fail(KH_ERR_HIP, "hipStreamQuery failed: %s", hipGetErrorString(q));
-        if ((k & 7) == 7) sched_yield();        // the callers' threads may need this core: poll, but never hog
-    }
-    if (b.flags_out[0] | b.flags_out[1]) s.flags_clean = false;
+    return KH_OK;
+}
+
+int co_finish_legal(CoBatch& b)
+{
+    b.W.reset();
+    if (b.flags_out[0] | b.flags_out[1]) b.lane->flags_clean = false;
     if (b.flags_out[0]) return fail(KH_ERR_NAN_POLICY, "inference policy output contains NaN");   // nn.cpp:176-177
     if (b.flags_out[1]) return fail(KH_ERR_NAN_VALUE, "inference value output contains NaN");     // nn.cpp:179-180
     return KH_OK;
 }
 
-void co_run_batch(kh_engine* e, CoBatch& b)
+// Starts a sealed batch.  Returns true when it is now on the device (records + legal actions, per-sample values: the
+// self-play path) and the dispatcher has to poll for it; false when it ran synchronously (plane submissions and the
+// reference's flattened value tensor go through infer_host: uploads, downloads and a stream wait) and `rc` is final.
+bool co_start(kh_engine* e, CoBatch& b, int& rc)
 {
     const int B = b.rows;
-    int rc;
     const bool flat = e->cfg.value_mode == KH_VALUE_REFERENCE_FLAT;
+    if (b.kind == 0 && !flat) {
+        rc = co_launch_legal(e, b);
+        if (rc) b.W.reset();
+        return rc == KH_OK;
+    }
     if (b.kind == 0) {
-        if (flat) {
-            // nn.cpp:186 hands back the first `batch` floats of the caller's OWN flattened [batch,256] tensor: take the
-            // whole tensor and cut each caller's slice out of it below
-            LegalIO l{ b.offsets, b.actions, b.priors };
-            b.vfull.resize((size_t)B * KH_VALUE_WIDTH);
-            rc = infer_host(e, nullptr, b.boards, B, nullptr, nullptr, b.vfull.data(), nullptr, &l);
-        } else {
-            rc = co_run_legal_direct(e, b);
-        }
+        // nn.cpp:186 hands back the first `batch` floats of the caller's OWN flattened [batch,256] tensor: take the
+        // whole tensor and cut each caller's slice out of it below
+        LegalIO l{ b.offsets, b.actions, b.priors };
+        b.vfull.resize((size_t)B * KH_VALUE_WIDTH);
+        rc = infer_host(e, nullptr, b.boards, B, nullptr, nullptr, b.vfull.data(), nullptr, &l);
     } else {
         b.policy.resize((size_t)B * KH_PSIZE);
         b.vfull.resize((size_t)B * KH_VALUE_WIDTH);
         rc = infer_host(e, b.planes.data(), nullptr, B, b.policy.data(), nullptr, b.vfull.data(), nullptr);
     }
+    return false;
+}
+
+// One ticket's rows out of a finished records-and-legal-actions batch's page-locked block (per-sample values)
+inline void co_fetch(CoTicket* t)
+{
+    const CoBatch* b = t->from;
+    if (t->nact) memcpy(t->priors, b->priors + t->act0, (size_t)t->nact * 4);
+    memcpy(t->value, b->values + t->row0, (size_t)t->rows * 4);
+}
+
+// the last ticket's rows are out: the buffer can be filled again
+void co_release(Coalescer* c, CoBatch* b)
+{
+    std::lock_guard<SpinLock> lk(c->mu);
+    b->tickets.clear();
+    b->rows = b->nact = 0; b->full = false; b->state = 0;
+    c->cv_space.notify_all();
+}
+
+// a ticket in state 4: whoever wins the claim copies its rows out (its waiter, or the dispatcher going round)
+inline bool co_claim_fetch(Coalescer* c, CoTicket* t)
+{
+    int expect = 4;
+    if (!t->state.compare_exchange_strong(expect, 5, std::memory_order_acquire)) return false;
+    CoBatch* b = t->from;
+    co_fetch(t);
+    t->state.store(2, std::memory_order_release);
+    if (b->readers.fetch_sub(1, std::memory_order_acq_rel) == 1) co_release(c, b);
+    return true;
+}
+
+// results (or the error) of a finished batch into every caller's own buffers, by the dispatcher alone: the synchronous
+// kinds, errors, and the rare per-ticket re-run
+void co_deliver(kh_engine* e, CoBatch& b, int rc)
+{
+    const bool flat = e->cfg.value_mode == KH_VALUE_REFERENCE_FLAT;
     const std::string err = rc ? g_err : std::string();
     for (CoTicket* t : b.tickets) {
         if (rc == KH_ERR_NAN_POLICY || rc == KH_ERR_NAN_VALUE) {
@@ -1120,62 +1205,134 @@ void co_run_batch(kh_engine* e, CoBatch& b)
     }
 }
 
-void co_lane(Coalescer* c)
+// ONE dispatcher thread per engine: seals a batch when the rule says so, launches it WITHOUT waiting for it, polls the
+// launches that are on the device (up to `max_inflight`, each on its buffer's own stream) and hands results back.
+// Round 2 had two lanes that each blocked on their launch: two spinning threads of the 16 the search needs, and a batch
+// that became ready while both were busy waited out a whole engine call.
+// Completion: signal_kernel's word in the batch's page-locked block (hipStreamQuery only as the safety net that notices
+// a failed stream).  Hand-back: a finished batch's tickets go to state 4 at once and every waiter copies its OWN rows
+// out of the block (a dozen callers in parallel: the block was written over PCIe, every line is a DRAM miss — one
+// thread copying 30 KB took 6-8 us of every caller's time); the dispatcher goes round the tickets nobody has claimed
+// yet, so a buffer comes back whether or not its callers are waiting.
+void co_dispatch(Coalescer* c)
 {
     kh_engine* e = c->e;
-    std::unique_lock<std::mutex> lk(c->mu);
-    for (;;) {
+    CoBatch* fly[CO_BUFFERS];
+    CoBatch* drain[CO_BUFFERS];                 // finished batches whose tickets may still be in state 4
+    int drain_age[CO_BUFFERS];
+    int nfly = 0, ndrain = 0;
+    auto us = [](std::chrono::steady_clock::duration d) { return std::chrono::duration<double, std::micro>(d).count(); };
+    auto complete = [&](CoBatch* b, int rc, bool in_block) {
+        const auto t_ran = std::chrono::steady_clock::now();
+        CoTicket* mine[KH_MAX_OUTSTANDING];
+        const int nt = (int)b->tickets.size();
+        for (int i = 0; i < nt; ++i) mine[i] = b->tickets[i];
+        const int rows = b->rows;
+        if (in_block && rc == KH_OK) {
+            b->readers.store(nt, std::memory_order_relaxed);
+            for (int i = 0; i < nt; ++i) { mine[i]->status = KH_OK; mine[i]->err.clear(); mine[i]->from = b; }
+            for (int i = 0; i < nt; ++i) mine[i]->state.store(4, std::memory_order_release);
+        } else {
+            co_deliver(e, *b, rc);
+            for (int i = 0; i < nt; ++i) mine[i]->state.store(2, std::memory_order_release);
+        }
+        bool wake;
+        {
+            std::lock_guard<SpinLock> lk(c->mu);
+            c->launches += 1; c->rows_launched += rows;
+            wake = c->sleepers > 0;
+        }
+        if (wake) c->cv_done.notify_all();          // (sleepers re-check their ticket under the lock: states were stored before it)
+        if (in_block && rc == KH_OK) {                          // its waiters fetch their rows; the dispatcher sweeps up later
+            int i = 0;
+            while (i < ndrain && drain[i] != b) ++i;            // (still listed from its previous launch: released since)
+            if (i == ndrain) ++ndrain;
+            drain[i] = b; drain_age[i] = 0;
+        }
+        else co_release(c, b);
+        if (c->trace) {
+            c->us_fill += us(b->t_seal - b->first); c->us_copywait += us(b->t_run - b->t_seal); c->us_launch += us(b->t_launched - b->t_run);
+            c->us_run += us(t_ran - b->t_run); c->us_finish += us(std::chrono::steady_clock::now() - t_ran);
+        }
+    };
+    for (unsigned spin = 0;; ++spin) {
         CoBatch* take = nullptr;
-        auto deadline = std::chrono::steady_clock::time_point::max();
-        const int target = e->co_target.load(), wait_us = e->co_wait_us.load();
-        for (auto& b : c->batches) {
-            if (b.state != 1 || b.rows == 0) continue;
-            // immediate mode (no target): whatever has accumulated goes as soon as a lane is free;
-            // target mode: wait for `target` rows — but no longer than wait_us after the batch's first submission, and
-            // not once the burst of submissions has ended (nothing added for wait_us / 8: callers that keep a fixed
-            // number of positions in flight rarely hit the target exactly — terminal leaves need no evaluation)
-            const int callers = e->co_callers.load();
-            bool ready = b.full || target <= 0 || b.rows >= target || (callers > 0 && (int)b.tickets.size() >= callers);
-            if (!ready) {
-                const auto due = std::min(b.first + std::chrono::microseconds(wait_us), b.last + std::chrono::microseconds(wait_us / 8 + 1));
-                if (std::chrono::steady_clock::now() >= due) ready = true;
-                else deadline = std::min(deadline, due);
+        {
+            std::unique_lock<SpinLock> lk(c->mu);
+            bool open_any = false;
+            const int target = e->co_target.load(), wait_us = e->co_wait_us.load(), callers = e->co_callers.load();
+            for (auto& b : c->batches) {
+                if (b.state != 1 || b.rows == 0) continue;
+                open_any = true;
+                if (nfly >= c->max_inflight) break;
+                // immediate mode (no target): whatever has accumulated goes at once;
+                // target mode: wait for `target` rows or `callers` submissions — but no longer than wait_us after the
+                // batch's first submission, and not once the burst of submissions has ended (nothing added for
+                // wait_us / 8: callers that keep a fixed number of positions in flight rarely hit the target exactly —
+                // terminal leaves need no evaluation)
+                bool ready = b.full || target <= 0 || b.rows >= target || (callers > 0 && (int)b.tickets.size() >= callers);
+                if (!ready) {
+                    const auto due = std::min(b.first + std::chrono::microseconds(wait_us), b.last + std::chrono::microseconds(wait_us / 8 + 1));
+                    ready = std::chrono::steady_clock::now() >= due;
+                }
+                if (ready) { take = &b; break; }
             }
-            if (ready) { take = &b; break; }
+            if (!take && !open_any && nfly == 0 && ndrain == 0) {
+                if (c->stop) return;
+                c->cv_lane.wait(lk);                 // nothing queued, nothing on the device
+                continue;
+            }
+            if (take) { take->state = 2; take->t_seal = std::chrono::steady_clock::now(); }
+        }
+        if (take) {
+            while (take->copying.load(std::memory_order_acquire) > 0) __builtin_ia32_pause();   // submitters still copying their rows in: a microsecond
+            take->t_run = std::chrono::steady_clock::now();
+            int rc = KH_OK;
+            int li = 0;
+            while (c->lane_busy[li]) ++li;              // nfly < max_inflight <= MAX_LANES: one is free
+            take->lane = &c->lanes[li];
+            const bool on_device = co_start(e, *take, rc);
+            if (on_device) c->lane_busy[li] = true;
+            take->t_launched = std::chrono::steady_clock::now();
+            if (on_device) fly[nfly++] = take;
+            else complete(take, rc, false);
+        }
+        for (int i = 0; i < nfly;) {
+            CoBatch* b = fly[i];
+            bool done = __atomic_load_n(b->done, __ATOMIC_ACQUIRE) == b->serial;
+            hipError_t q = hipSuccess;
+            if (!done && (spin & 4095) == 4095) {         // safety net: a stream that failed never writes the word
+                q = hipStreamQuery(b->lane->stream);
+                done = q != hipErrorNotReady;
+            }
+            if (!done) { ++i; continue; }
+            const int rc = q == hipSuccess ? co_finish_legal(*b) : fail(KH_ERR_HIP, "hipStreamQuery failed: %s", hipGetErrorString(q));
+            b->W.reset();
+            c->lane_busy[b->lane - c->lanes] = false;
+            complete(b, rc, true);
+            fly[i] = fly[--nfly];
+        }
+        // Finished batches whose rows have not all been fetched: their waiters do that themselves, in parallel, the
+        // moment they see state 4 — the dispatcher only sweeps up what is left after a few rounds' grace (callers that
+        // are busy with another set, or never wait), so that a buffer always comes back.  A buffer is in the list at
+        // most once (a second publish needs a release in between), so the list never outgrows the buffers.
+        for (int i = 0; i < ndrain;) {
+            CoBatch* b = drain[i];
+            if (b->readers.load(std::memory_order_acquire) > 0 && (take || ++drain_age[i] <= 16)) { ++i; continue; }
+            if (b->readers.load(std::memory_order_acquire) > 0) {
+                CoTicket* mine[KH_MAX_OUTSTANDING];
+                int nt = 0;
+                { std::lock_guard<SpinLock> lk(c->mu); if (b->state == 2) for (CoTicket* t : b->tickets) mine[nt++] = t; }
+                for (int k = 0; k < nt; ++k) if (mine[k]->from == b) (void)co_claim_fetch(c, mine[k]);
+            }
+            --ndrain;
+            drain[i] = drain[ndrain]; drain_age[i] = drain_age[ndrain];
         }
         if (!take) {
-            if (c->stop) return;
-            if (deadline == std::chrono::steady_clock::time_point::max()) c->cv_lane.wait(lk);
-            else {
-                // a batch is filling and will go within wait_us at the latest: poll for it instead of sleeping — the
-                // wake-up of a sleeping lane (5-15 us) would be paid by every caller of the launch
-                lk.unlock();
-                for (int k = 0; k < 32; ++k) __builtin_ia32_pause();
-                sched_yield();
-                lk.lock();
-            }
-            continue;
-        }
-        take->state = 2;
-        ++c->lanes_busy;
-        const auto t_seal = std::chrono::steady_clock::now();
-        lk.unlock();
-        while (take->copying.load(std::memory_order_acquire) > 0) __builtin_ia32_pause();   // submitters still copying their rows in: a microsecond
-        const auto t_run = std::chrono::steady_clock::now();
-        co_run_batch(e, *take);
-        const auto t_ran = std::chrono::steady_clock::now();
-        lk.lock();
-        --c->lanes_busy;
-        c->launches += 1; c->rows_launched += take->rows;
-        for (CoTicket* t : take->tickets) t->state.store(2, std::memory_order_release);
-        take->tickets.clear();
-        take->rows = take->nact = 0; take->full = false; take->state = 0;
-        if (c->sleepers) c->cv_done.notify_all();
-        c->cv_space.notify_all();
-        if (c->trace) {
-            auto us = [](std::chrono::steady_clock::duration d) { return std::chrono::duration<double, std::micro>(d).count(); };
-            c->us_fill += us(t_seal - take->first); c->us_copywait += us(t_run - t_seal); c->us_run += us(t_ran - t_run);
-            c->us_finish += us(std::chrono::steady_clock::now() - t_ran);
+            // a batch is filling or a launch is on the device: poll (a sleeping thread's wake-up, 5-15 us, would be
+            // paid by every caller of the launch), but let a caller's thread have the core when it needs one
+            for (int k = 0; k < 8; ++k) __builtin_ia32_pause();
+            if ((spin & 15) == 15) sched_yield();
         }
     }
 }
@@ -1188,10 +1345,13 @@ Coalescer* co_get(kh_engine* e)
         c->e = e;
         c->trace = getenv("KAMI_CO_TRACE") != nullptr;
         if (getenv("KAMI_WAIT_SPIN_US")) c->spin_us = std::max(0, atoi(getenv("KAMI_WAIT_SPIN_US")));
-        int nl = 2;
-        if (getenv("KAMI_CO_LANES")) nl = std::min(CO_LANES, std::max(1, atoi(getenv("KAMI_CO_LANES"))));
-        for (int i = 0; i < nl; ++i) c->lanes[i] = std::thread(co_lane, c);
+        if (getenv("KAMI_CO_INFLIGHT")) c->max_inflight = std::min((int)Coalescer::MAX_LANES, std::max(1, atoi(getenv("KAMI_CO_INFLIGHT"))));
+        // the lanes' streams now, one after the other (see Coalescer::lanes); a failure here shows up at the first launch
+        if (set_device(e) == KH_OK)
+            for (auto& l : c->lanes) (void)hipStreamCreateWithFlags(&l.stream, hipStreamNonBlocking);
+        c->dispatcher = std::thread(co_dispatch, c);
         e->co = c;
+        e->co_ready.store(c, std::memory_order_release);
     }
     return e->co;
 }
@@ -1200,19 +1360,20 @@ void co_destroy(kh_engine* e)
 {
     Coalescer* c = e->co;
     if (!c) return;
-    { std::lock_guard<std::mutex> lk(c->mu); c->stop = true; }
+    { std::lock_guard<SpinLock> lk(c->mu); c->stop = true; }
     c->cv_lane.notify_all();
-    for (auto& l : c->lanes) if (l.joinable()) l.join();
+    if (c->dispatcher.joinable()) c->dispatcher.join();
     (void)hipSetDevice(e->cfg.device);
-    for (auto& b : c->batches) {
-        if (b.slot.stream) { (void)hipStreamSynchronize(b.slot.stream); (void)hipStreamDestroy(b.slot.stream); b.slot.stream = nullptr; }
+    for (auto& l : c->lanes) {
+        if (l.stream) { (void)hipStreamSynchronize(l.stream); (void)hipStreamDestroy(l.stream); l.stream = nullptr; }
     }
     if (c->trace && c->launches)
         fprintf(stderr, "[kami queue] %lld launches, %.1f rows each; per launch: filling %.1f us, waiting for copies %.1f us, "
-                "engine call %.1f us, hand-back %.1f us\n", (long long)c->launches, (double)c->rows_launched / c->launches,
-                c->us_fill / c->launches, c->us_copywait / c->launches, c->us_run / c->launches, c->us_finish / c->launches);
+                "engine call %.1f us (of which the launch call %.1f), hand-back %.1f us\n", (long long)c->launches, (double)c->rows_launched / c->launches,
+                c->us_fill / c->launches, c->us_copywait / c->launches, c->us_run / c->launches, c->us_launch / c->launches, c->us_finish / c->launches);
     delete c;
     e->co = nullptr;
+    e->co_ready.store(nullptr, std::memory_order_release);
 }
 
 int co_submit(kh_engine* e, int kind, const kh_board* boards, const float* planes, int batch, const int32_t* offsets,
@@ -1232,11 +1393,12 @@ int co_submit(kh_engine* e, int kind, const kh_board* boards, const float* plane
         if (!planes || !policy) return fail(KH_ERR_INVALID, "null buffer");
         if (batch > CO_SMALL_PLANES) return fail(KH_ERR_INVALID, "plane submissions hold at most %d positions (use kh_infer for more)", CO_SMALL_PLANES);
     }
-    if (!current_weights(e)) return fail(KH_ERR_NO_WEIGHTS, "submit before kh_load_weights");
-    Coalescer* c = co_get(e);
+    if (!e->has_weights.load(std::memory_order_acquire)) return fail(KH_ERR_NO_WEIGHTS, "submit before kh_load_weights");   // (no shared_ptr copy under wmu per submission)
+    Coalescer* c = e->co_ready.load(std::memory_order_acquire);
+    if (!c) c = co_get(e);
     const size_t F = e->cfg.features;
     const int cap_rows = kind == 0 ? CO_ROWS : 2 * CO_SMALL_PLANES;
-    std::unique_lock<std::mutex> lk(c->mu);
+    std::unique_lock<SpinLock> lk(c->mu);
     CoTicket* t = nullptr;
     int tid = 0;
     for (; tid < KH_MAX_OUTSTANDING; ++tid)
@@ -1261,7 +1423,7 @@ int co_submit(kh_engine* e, int kind, const kh_board* boards, const float* plane
                 if (!b->boards) {
                     const size_t o_offs = (size_t)CO_ROWS * sizeof(kh_board), o_acts = o_offs + (((size_t)CO_ROWS + 1) * 4 + 15) / 16 * 16;
                     const size_t o_vals = (size_t)CO_ACTS * 4, o_flags = o_vals + (size_t)CO_ROWS * 4;
-                    if (set_device(e) || b->pin_in.ensure(o_acts + (size_t)CO_ACTS * 4) || b->pin_out.ensure(o_flags + 16)) {
+                    if (set_device(e) || b->pin_in.ensure(o_acts + (size_t)CO_ACTS * 4) || b->pin_out.ensure(o_flags + 128)) {
                         b->state = 0;
                         t->state.store(0, std::memory_order_release);
                         return KH_ERR_HIP;
@@ -1272,6 +1434,8 @@ int co_submit(kh_engine* e, int kind, const kh_board* boards, const float* plane
                     b->priors = reinterpret_cast<float*>(b->pin_out.at(0));
                     b->values = reinterpret_cast<float*>(b->pin_out.at(o_vals));
                     b->flags_out = reinterpret_cast<int*>(b->pin_out.at(o_flags));
+                    b->done = reinterpret_cast<unsigned*>(b->pin_out.at(o_flags + 64));       // a cache line of its own
+                    *b->done = 0;
                 }
                 b->offsets[0] = 0;
             } else if (b->planes.size() < (size_t)cap_rows * 64 * F) b->planes.resize((size_t)cap_rows * 64 * F);
@@ -1315,21 +1479,33 @@ int co_wait(kh_engine* e, int64_t ticket)
     if (t.state.load(std::memory_order_acquire) == 0 || t.serial != serial)
         return fail(KH_ERR_INVALID, "ticket already waited for (or never issued)");
     // a launch is ~100 us away at most: spin on the ticket first (no wake-up latency, no mutex convoy when a launch
-    // releases many callers at once), sleep on the condition variable only when it takes longer
-    if (t.state.load(std::memory_order_acquire) != 2 && c->spin_us > 0) {
+    // releases many callers at once), sleep on the condition variable only when it takes longer.  State 4: the rows are
+    // in the batch's block and this thread fetches them itself (unless the dispatcher got there first: state 5, then 2).
+    auto settled = [&] {
+        const int st = t.state.load(std::memory_order_acquire);
+        if (st == 2) return true;
+        if (st == 4) (void)co_claim_fetch(c, &t);
+        return t.state.load(std::memory_order_acquire) == 2;
+    };
+    if (!settled() && c->spin_us > 0) {
         const auto until = std::chrono::steady_clock::now() + std::chrono::microseconds(c->spin_us);
-        for (int k = 0; t.state.load(std::memory_order_acquire) != 2; ++k) {
+        for (int k = 0; !settled(); ++k) {
             __builtin_ia32_pause();
             if ((k & 63) == 63) {
-                sched_yield();                  // lets a launch lane (or another caller) have the core if it needs one
+                sched_yield();                  // lets the dispatcher (or another caller) have the core if it needs one
                 if (std::chrono::steady_clock::now() >= until) break;
             }
         }
     }
-    if (t.state.load(std::memory_order_acquire) != 2) {
-        std::unique_lock<std::mutex> lk(c->mu);
+    if (!settled()) {
+        std::unique_lock<SpinLock> lk(c->mu);
         ++c->sleepers;
-        while (t.state.load(std::memory_order_acquire) != 2) c->cv_done.wait(lk);
+        for (;;) {
+            const int st = t.state.load(std::memory_order_acquire);
+            if (st == 2) break;
+            if (st == 4 || st == 5) { lk.unlock(); while (!settled()) __builtin_ia32_pause(); lk.lock(); break; }
+            c->cv_done.wait(lk);
+        }
         --c->sleepers;
     }
     const int rc = t.status;
@@ -1437,6 +1613,7 @@ int kh_load_weights(kh_engine* e, const float* blob, size_t nfloats, int generat
     }
     std::lock_guard<std::mutex> lk(e->wmu);
     e->weights = W;                  // calls in flight keep their own reference
+    e->has_weights.store(true, std::memory_order_release);
     return KH_OK;
 }
 
@@ -1718,6 +1895,23 @@ int kh_submit_encode_infer_legal(kh_engine* e, const kh_board* boards, int batch
 
 int kh_wait(kh_engine* e, int64_t ticket) { return co_wait(e, ticket); }
 
+int kh_try_wait(kh_engine* e, int64_t ticket, int* done)
+{
+    if (!done) return fail(KH_ERR_INVALID, "null done");
+    *done = 0;
+    if (!e || !e->co) return fail(KH_ERR_INVALID, "no such ticket");
+    Coalescer* c = e->co;
+    const int tid = (int)(ticket & 0xffffffff);
+    if (tid < 0 || tid >= KH_MAX_OUTSTANDING) return fail(KH_ERR_INVALID, "no such ticket");
+    CoTicket& t = c->tickets[tid];
+    int st = t.state.load(std::memory_order_acquire);
+    if (st == 0 || t.serial != (uint32_t)(ticket >> 32)) return fail(KH_ERR_INVALID, "ticket already waited for (or never issued)");
+    if (st == 4) { (void)co_claim_fetch(c, &t); st = t.state.load(std::memory_order_acquire); }
+    if (st != 2) return KH_OK;                  // queued, on the device, or the dispatcher is copying its rows right now
+    *done = 1;
+    return co_wait(e, ticket);                  // settled: returns at once with the ticket's status
+}
+
 int kh_set_coalesce(kh_engine* e, int target_batch, int max_wait_us)
 {
     if (!e || target_batch < 0 || target_batch > CO_ROWS || max_wait_us < 0 || max_wait_us > 1000000)
@@ -1731,6 +1925,7 @@ int kh_set_coalesce(kh_engine* e, int target_batch, int max_wait_us)
 int kh_set_coalesce_callers(kh_engine* e, int callers)
 {
     if (!e || callers < 0 || callers > KH_MAX_OUTSTANDING) return fail(KH_ERR_INVALID, "callers in [0, %d]", KH_MAX_OUTSTANDING);
+    if (callers > 0 && getenv("KAMI_CO_CALLERS") && atoi(getenv("KAMI_CO_CALLERS")) > 0) callers = std::min(callers, atoi(getenv("KAMI_CO_CALLERS")));   // A/B knob: seal at fewer submissions
     e->co_callers = callers;
     if (e->co) e->co->cv_lane.notify_all();
     return KH_OK;
@@ -1740,7 +1935,7 @@ int kh_coalesce_stats(kh_engine* e, int64_t* launches, int64_t* rows)
 {
     if (!e) return fail(KH_ERR_INVALID, "null engine");
     int64_t l = 0, r = 0;
-    if (e->co) { std::lock_guard<std::mutex> lk(e->co->mu); l = e->co->launches; r = e->co->rows_launched; }
+    if (e->co) { std::lock_guard<SpinLock> lk(e->co->mu); l = e->co->launches; r = e->co->rows_launched; }
     if (launches) *launches = l;
     if (rows) *rows = r;
     return KH_OK;

@@ -18,6 +18,9 @@ void launch_gather_legal(const float* policy, const int32_t* offsets, const int3
                          float* priors, int B, hipStream_t s, const float* vfull = nullptr, int vstride = 0,
                          float* values = nullptr, const int* flags_in = nullptr, int* flags_out = nullptr);
 
+// stores `serial` to a word of page-locked host memory once the stream's earlier work has finished
+void launch_signal(unsigned* host_word, unsigned serial, hipStream_t s);
+
 // ---- forward_simple.hip -----------------------------------------------------------------
 // Plain fp32 VALU kernels, one launch per layer.  Exact-order fp32 (same tap-major,
 // channel-inner accumulation order as the CPU oracle); the correctness anchor on device.

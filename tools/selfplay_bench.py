@@ -17,7 +17,9 @@ CASES = [  # games, threads, leaves/tree, visits/move, pipeline, coalesce target
     # many trees, one leaf each (the reference's schedule, more games)
     (8192, 16, 1, 64, 0, 0, 0), (8192, 14, 1, 64, 1, 1024, 100), (4096, 14, 2, 64, 1, 1024, 100),
 ]
-if len(sys.argv) > 2:
+if os.environ.get("SP_CASE"):          # one ad-hoc case: "games,threads,leaves,visits,pipeline,target,wait"
+    CASES = [tuple(int(x) for x in os.environ["SP_CASE"].split(","))]
+elif len(sys.argv) > 2:
     CASES = CASES[int(sys.argv[1]):int(sys.argv[2])]
 elif len(sys.argv) > 1:
     CASES = CASES[:int(sys.argv[1])]
