@@ -221,14 +221,15 @@ int  kh_wait(kh_engine* e, int64_t ticket);
  * valid).  For a caller with several tickets in flight that wants whichever finishes first (the self-play pool's
  * workers: launches do not complete in submission order once several are on the device). */
 int  kh_try_wait(kh_engine* e, int64_t ticket, int* done);
-/* Launch policy of the queue.  target_batch 0 (default): whatever has accumulated goes as soon as a launch lane is
- * free.  target_batch > 0: a batch waits until it holds that many positions, but at most max_wait_us after its first
+/* Launch policy of the queue.  target_batch 0 (default): whatever has accumulated goes as soon as one of the queue's
+ * four launch streams is free.  target_batch > 0: a batch waits until it holds that many positions, but at most max_wait_us after its first
  * submission and no longer than max_wait_us / 8 after its latest one (the burst has ended) — for callers that know how
  * many positions they keep in flight (the self-play pool). */
 int  kh_set_coalesce(kh_engine* e, int target_batch, int max_wait_us);
 /* With a target set: a batch also goes as soon as it holds `callers` submissions (0, the default: rule off) — for a pool
- * whose every worker submits once per round, the round is complete then, whatever its size (terminal leaves need no
- * evaluation, so rounds rarely reach the target exactly). */
+ * whose every worker submits once per round: `callers` = the workers is a whole round whatever its size (terminal leaves
+ * need no evaluation, so rounds rarely reach the target exactly); half of them (what ks_pool_run sets) lets the early
+ * half go without waiting for the slowest worker. */
 int  kh_set_coalesce_callers(kh_engine* e, int callers);
 /* launches made by the queue so far and the positions they held (mean coalesced batch = rows / launches) */
 int  kh_coalesce_stats(kh_engine* e, int64_t* launches, int64_t* rows);

@@ -532,7 +532,7 @@ struct kh_engine {
     std::unique_ptr<Slot> devslot;           // scratch for the device-pointer API
     std::mutex dmu;
     Coalescer* co = nullptr;          // submit / wait queue (created on first use)
-    std::atomic<Coalescer*> co_ready{ nullptr };     // the same pointer once the lanes run: submitters skip co_mu
+    std::atomic<Coalescer*> co_ready{ nullptr };     // the same pointer once the dispatcher runs: submitters skip co_mu
     std::atomic<bool> has_weights{ false };
     std::mutex co_mu;
     std::atomic<int> small_calls{ 0 };       // synchronous small-batch calls currently inside the engine
@@ -972,15 +972,16 @@ int infer_host(kh_engine* e, const float* input, const kh_board* boards, int bat
 // SURVEY §8(b), threading row: "per-thread stream + staging slot, OR internal queue that coalesces callers into
 // bigger batches".  The slots above are the first; this is the second.  Callers hand over small batches
 // (kh_submit_* returns a ticket at once, kh_wait blocks for it; the synchronous entry points use the same queue when
-// other small calls are in flight), each caller copies its own rows into the open batch's merge buffers, and two lane
-// threads turn whatever has accumulated into ONE launch each (one pinned block each way, infer_host's packed path),
-// then scatter priors / policy rows / values straight into the callers' buffers.  While a launch is in flight the
-// next batch fills up, so the batch size adapts to the load; kh_set_coalesce adds a target size and a bounded wait
-// for callers that know how much will be in flight (the self-play pool).
+// other small calls are in flight), each caller copies its own rows into the open batch's merge buffers, and ONE
+// dispatcher thread turns whatever has accumulated into a launch on one of four streams without waiting for it (one
+// pinned block each way), polls the launches' completion words and publishes the results: every waiter copies its own
+// rows out of the block.  While launches are on the device the next batch fills up, so the batch size adapts to the
+// load; kh_set_coalesce adds a target size and a bounded wait for callers that know how much will be in flight (the
+// self-play pool).
 //
 // Never blocks a submitter on its own outstanding work: tickets are a fixed pool (exhaustion -> KH_ERR_INVALID),
-// merge buffers are handed back as soon as their launch has completed (results are already in the callers'
-// buffers), so the only wait inside kh_submit_* is for a launch that is already on the device.
+// merge buffers come back when their launch has completed and its rows have been fetched — by the waiters, or by the
+// dispatcher for tickets nobody waits on — so the only wait inside kh_submit_* is for launches that are on the device.
 constexpr int CO_ROWS = 1024;                   // boards per coalesced launch (merge buffer capacity)
 constexpr int CO_ACTS = CO_ROWS * 48;           // legal actions per coalesced launch
 constexpr int CO_SMALL_LEGAL = 512;             // a submission larger than this takes the direct path

@@ -60,9 +60,15 @@ class Ticket:
         _chk(self._nn._lib.kh_wait(self._nn._h, self._t))
         return self._out
 
+    def try_wait(self):
+        """kh_try_wait: the outputs if the submission has finished (the ticket is consumed, as by wait()), else None."""
+        done = C.c_int(0)
+        _chk(self._nn._lib.kh_try_wait(self._nn._h, self._t, C.byref(done)))
+        return self._out if done.value else None
+
 
 # engines still open when the interpreter exits are closed while the HIP runtime is still up (module teardown order
-# is arbitrary otherwise, and an engine owns streams, launch-lane threads and device memory)
+# is arbitrary otherwise, and an engine owns streams, the queue's dispatcher thread and device memory)
 import atexit
 import weakref
 

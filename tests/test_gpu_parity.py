@@ -486,6 +486,39 @@ def test_submit_never_blocks_on_the_callers_own_tickets():
     assert np.array_equal(p, want[0])
 
 
+def test_try_wait_takes_tickets_in_completion_order():
+    """kh_try_wait: None while a submission is queued or on the device (the ticket stays valid), the synchronous call's
+    bits once it has finished (the ticket is consumed: a second poll or a wait fails); a caller can hold several tickets
+    and take whichever comes back first — what the pool's workers do."""
+    import time
+    F, C, R = 30, 64, 2
+    nn = NN(8, 8, F, 4672, filters=C, residuals=R, dtype="bf16", value_mode=L.KH_VALUE_PER_SAMPLE0)
+    nn.load_weights(W.random_weights(F, C, R, seed=5, peaky=10.0), 1)
+    cases = [_legal_case(20 + 7 * i, 300 + i) for i in range(6)]
+    want = [nn.infer_legal(*c) for c in cases]
+    # held back by a target nobody reaches: not done until the half-second limit has passed
+    nn.set_coalesce(1024, 500000)
+    t0 = time.perf_counter()
+    held = nn.submit_infer_legal(*cases[0])
+    assert held.try_wait() is None and time.perf_counter() - t0 < 0.3
+    nn.set_coalesce(0, 0)
+    p, v = held.wait()
+    assert np.array_equal(p, want[0][0]) and np.array_equal(v, want[0][1])
+    for _ in range(20):
+        tickets = {i: nn.submit_infer_legal(*cases[i]) for i in range(6)}
+        deadline = time.perf_counter() + 10.0
+        while tickets and time.perf_counter() < deadline:
+            for i in list(tickets):
+                out = tickets[i].try_wait()
+                if out is None:
+                    continue
+                assert np.array_equal(out[0], want[i][0]) and np.array_equal(out[1], want[i][1])
+                with pytest.raises(KamiError):
+                    tickets[i].try_wait()
+                del tickets[i]
+        assert not tickets
+
+
 def test_a_launch_goes_when_every_caller_has_submitted():
     """kh_set_coalesce_callers: with a target the round would otherwise wait out (target 512, half a second), a batch
     that holds a submission of each of the 3 callers goes at once; with the rule off the same round waits for the
