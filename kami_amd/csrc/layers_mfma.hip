@@ -1312,13 +1312,18 @@ struct ConvArgsF32 {
 // EPI: 0 = ReLU; 1 = ReLU, + skip (nn.cpp:31); 2 = raw fp32 logits, planes < 73 (nn.cpp:75-79);
 //      3 = raw (training: the convolution + bias, BatchNorm follows in its own kernels); 4 = raw, added to what
 //      `out` already holds (training: a data gradient that joins another one)
-template <int TAPS, int EPI>
+// PLAIN: one staged slice (Ci <= 128), whole 64-channel blocks (Co % 64 == 0) and a shift vector — the inference shapes
+// of a <= 128-filter net.  The general form (slice loop with a run-time trip count, partial channel blocks, optional
+// shift: added in round 2 for 256 filters and the trainer) made the SAME arithmetic 6-8 % slower at 64 filters
+// (conv_f32_kernel<9,0> 29.6 -> 32.0 us per layer at batch 512, same box, profiles/r03_f32_ab.txt): the branches are
+// compile-time here and the generated loop is round 1's again.
+template <int TAPS, int EPI, bool PLAIN = false>
 __global__ __launch_bounds__(256) void conv_f32_kernel(ConvArgsF32 a)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 5;
     const int Ci = a.Ci, Co = a.Co;
-    const int CS = Ci < 128 ? Ci : 128;                   // channels of one staged slice (Ci > 128: several passes)
+    const int CS = PLAIN ? Ci : (Ci < 128 ? Ci : 128);                   // channels of one staged slice (Ci > 128: several passes)
     const int stride = CS * 4 + 16;                       // (CS/4 + 1) 16-byte slots: odd -> conflict-free
     const int npx = (TAPS == 9) ? NPIX : 64;
     const int board_bytes = npx * stride;
@@ -1344,16 +1349,17 @@ __global__ __launch_bounds__(256) void conv_f32_kernel(ConvArgsF32 a)
         for (int g = 0; g < 4; ++g) {
             float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
             const int c0 = cb * 64 + ms * 32 + 8 * g + 4 * h;
-            if (a.shift) {
+            if (PLAIN) s = *reinterpret_cast<const float4*>(a.shift + c0);
+            else if (a.shift) {
                 if (c0 + 3 < Co) s = *reinterpret_cast<const float4*>(a.shift + c0);
                 else { if (c0 < Co) s.x = a.shift[c0]; if (c0 + 1 < Co) s.y = a.shift[c0 + 1]; if (c0 + 2 < Co) s.z = a.shift[c0 + 2]; }
             }
             acc[ms][4 * g + 0] = s.x; acc[ms][4 * g + 1] = s.y; acc[ms][4 * g + 2] = s.z; acc[ms][4 * g + 3] = s.w;
         }
     using f32x4v = __attribute__((ext_vector_type(4))) float;
-    for (int c_lo = 0; c_lo < Ci; c_lo += 128) {
-        const int cs = Ci - c_lo < 128 ? Ci - c_lo : 128, KJ = cs / 8, TK = TAPS * KJ;
-        if (c_lo) __syncthreads();                        // everybody is done reading the previous slice
+    for (int c_lo = 0; c_lo < (PLAIN ? 1 : Ci); c_lo += 128) {
+        const int cs = PLAIN ? Ci : (Ci - c_lo < 128 ? Ci - c_lo : 128), KJ = cs / 8, TK = TAPS * KJ;
+        if (!PLAIN && c_lo) __syncthreads();              // everybody is done reading the previous slice
         {
             const int CH = cs / 4;
             for (int i = tid; i < 2 * 64 * CH; i += 256) {
@@ -1427,7 +1433,7 @@ __global__ __launch_bounds__(256) void conv_f32_kernel(ConvArgsF32 a)
 #pragma unroll
                     for (int i = 0; i < 4; ++i) v[i] = relu_keep_nan(v[i]);
                 }
-                if (ch + 3 < Co && (Co & 3) == 0) {
+                if (PLAIN || (ch + 3 < Co && (Co & 3) == 0)) {
                     if (EPI == 1) {
                         const float4 s = *reinterpret_cast<const float4*>(a.skip + o);
                         v[0] += s.x; v[1] += s.y; v[2] += s.z; v[3] += s.w;
@@ -1611,6 +1617,19 @@ template <int TAPS, int EPI> static hipError_t launch_conv_f32(const ConvArgsF32
             }
             const int lds1 = std::max(lds / 2, 2 * 64 * 16 * 4);
             hipLaunchKernelGGL((conv_f32_small_kernel<TAPS, EPI>), dim3(a.B, (a.Co + 31) / 32), dim3(256), lds1, s, a);
+            return hipGetLastError();
+        }
+    }
+    if constexpr (EPI <= 2) {
+        if (a.Ci <= 128 && a.Co % 64 == 0 && a.shift) {
+            static std::atomic<bool> attr3_done{ false };
+            if (!attr3_done.load(std::memory_order_acquire)) {
+                hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_f32_kernel<TAPS, EPI, true>),
+                                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+                if (e != hipSuccess) return e;
+                attr3_done.store(true, std::memory_order_release);
+            }
+            hipLaunchKernelGGL((conv_f32_kernel<TAPS, EPI, true>), dim3((a.B + 1) / 2, a.Co / 64), dim3(256), lds, s, a);
             return hipGetLastError();
         }
     }

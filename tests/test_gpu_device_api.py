@@ -113,3 +113,45 @@ def test_encode_device_equals_encode(observe_fixture):
         torch.cuda.synchronize(); assert nn._lib.kh_sync(nn.handle) == 0
         assert same_bits(d_x.get((len(boards), 1920)), f["obs"].astype(np.float32))
     d_b.free(); d_x.free(); nn.close()
+
+
+_VARIANT_SCRIPT = r"""
+import sys, numpy as np
+from kami_amd import NN, weights as W
+out = sys.argv[1]
+res = {}
+for F, B, dtype in ((119, 37, "bf16"), (30, 64, "bf16"), (119, 16, "f16")):
+    nn = NN(8, 8, F, 4672, filters=64, residuals=6, dtype=dtype)
+    nn.load_weights(W.random_weights(F, 64, 6, seed=11, peaky=8.0), 1)
+    x = np.random.default_rng(F + B).random((B, 8, 8, F), dtype=np.float32)
+    p, v, _ = nn.infer_full(x, want_logits=False)
+    res[f"p_{F}_{B}_{dtype}"], res[f"v_{F}_{B}_{dtype}"] = p, v
+    nn.close()
+np.savez(out, **res)
+"""
+
+
+def test_both_whole_network_kernels_agree(tmp_path):
+    """`tower8_kernel` (round 3, the default) against `tower_kernel` (rounds 1-2, KAMI_TOWER_V=4): the variant is read
+    once per process, so each runs in a process of its own on the same weights and planes.  Same tiling and arithmetic;
+    the 119-plane stem sums its reduction in another order (four unpadded passes instead of two padded halves) and the
+    softmax another tree, and a different fp32 sum can round an activation to the neighbouring bf16: observed 2.0e-5
+    on probabilities up to 0.3 (relative 1e-4) / 9e-5 on values with these peaky weights, bit-identical at 30 planes
+    — three orders of magnitude inside the bf16 tolerances against the fp32 oracle (TOL_BY_DEPTH in test_gpu_parity.py:
+    12 % relative on probabilities, 2e-3 on values), which every parity test checks on the default kernel."""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    outs = {}
+    for v in ("4", "8"):
+        path = str(tmp_path / f"v{v}.npz")
+        env = dict(os.environ, KAMI_TOWER_V=v, PYTHONPATH=root + os.pathsep + os.environ.get("PYTHONPATH", ""))
+        r = subprocess.run([sys.executable, "-c", _VARIANT_SCRIPT, path], env=env, cwd=root, capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stderr[-2000:]
+        outs[v] = np.load(path)
+    for k in outs["4"].files:
+        a, b = outs["4"][k], outs["8"][k]
+        tol = 1e-4 if k.startswith("p_") else 1e-3
+        assert np.isfinite(a).all() and np.isfinite(b).all()
+        assert np.abs(a - b).max() <= tol, (k, float(np.abs(a - b).max()))
+        if "_30_" in k:
+            assert same_bits(a, b), k
