@@ -479,7 +479,7 @@ int build_simple(Weights& W, const HostNet& n, int F, int C, int R)
 struct Slot {
     hipStream_t stream = nullptr;
     int cap = 0;                 // boards the scratch is sized for
-    DevMem in, x, t, u, ph, logits, policy, v64, vfull, flags, boards, planes, offs, acts, priors, actin;
+    DevMem in, x, t, u, ph, logits, policy, v64, vfull, flags, boards, planes, offs, acts, priors, actin, xchg;
     DevMem pack_in, pack_out;    // legal-move host path: arguments / results packed for one copy each way
     PinMem hin, hout;
     hipStream_t stream2 = nullptr;   // registered caller buffers: chunks alternate between the two streams
@@ -700,6 +700,16 @@ int forward_layers(kh_engine* e, const Weights& W, Slot& s, const float* d_in, i
     L.w2b = W.ly_w2b_ok ? W.ly_w2b.as<unsigned short>() : nullptr;
     L.policy = d_policy; L.flags = flags; L.want_logits = d_logits_out != nullptr;
     L.fcw = W.ly_misc.as<float>() + W.ly_CP; L.fcb = L.fcw + (size_t)KH_VALUE_WIDTH * 64; L.vfull = d_vfull;
+    L.num_cus = e->num_cus;
+    if (W.ly_CP == 256 && W.ly_w2b_ok && e->cfg.dtype != KH_F32 && 16 * (((B + 1) / 2 + 7) / 8) <= e->num_cus) {
+        // tower2s_kernel's exchange area (two workgroups per board pair at batches that leave half the chip idle)
+        const int pairs_cap = e->num_cus / 2;
+        if (s.xchg.ensure(kh::layers_xchg_bytes(pairs_cap)) == KH_OK) {
+            L.xflag = s.xchg.as<unsigned>();
+            L.xbuf = reinterpret_cast<unsigned short*>(static_cast<char*>(s.xchg.p) + kh::layers_xflag_bytes(pairs_cap));
+            L.x_pairs = pairs_cap;
+        }
+    }
     HIPCHK(kh::launch_layers(e->cfg.dtype, L, st));              // tower, policy head + softmax (nn.cpp:72-80), value head (nn.cpp:83-88)
     HIPCHK(hipGetLastError());
     return KH_OK;

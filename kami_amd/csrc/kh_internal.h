@@ -108,8 +108,16 @@ struct LayersArgs {
     const float* fcw;              // valuefc.weight [256][64], .bias [256] (device); launch_layers runs the value FC too
     const float* fcb;
     float* vfull;                  // [B][256]
+    // tower2s_kernel's exchange area (nullable): [x_pairs][2] flags 64 bytes apart, then [2][x_pairs][2][128][128] T
+    unsigned* xflag = nullptr;
+    unsigned short* xbuf = nullptr;
+    int x_pairs = 0;
+    int num_cus = 256;
 };
 size_t layers_lds_bytes(int Ci);
+// bytes of the exchange area for up to `pairs` board pairs: flags first (the block the launcher zeroes), then the images
+constexpr size_t layers_xflag_bytes(int pairs) { return (size_t)pairs * 2 * 64; }
+constexpr size_t layers_xchg_bytes(int pairs) { return layers_xflag_bytes(pairs) + (size_t)2 * pairs * 2 * 128 * 128 * 2; }
 // exact-fp32 MFMA convolution (conv_f32_kernel) for the trainer: out [B][64][Co] = conv(in [B][64][Ci]) + bias (nullable),
 // or out += conv(in) when `accumulate`.  packed_w: fragments in conv_f32_kernel's order, Co rounded up to 64,
 // [Co/64][Ci slices of <= 128][taps][slice/8][2][64 lanes][4] (train.hip packs them on the device).  Ci % 8 == 0.

@@ -36,6 +36,11 @@ using u32x4 = __attribute__((ext_vector_type(4))) unsigned;
 using u32x2 = __attribute__((ext_vector_type(2))) unsigned;
 using f32x4s = __attribute__((ext_vector_type(4))) float;
 
+#ifndef KAMI_SPLIT_MIN_B
+#define KAMI_SPLIT_MIN_B 1           // 256 filters: smallest batch on tower2s_kernel (against the per-layer kernels, 20x256 f16: 439 vs 480 us at
+                                    // batch 1, 449 vs 499 at 32, 456 vs 564 at 128, 641 vs 972 at 254: it wins everywhere, so one kernel family — one
+                                    // summation order — serves every batch up to 256)
+#endif
 constexpr int PITCH = 12;
 constexpr int NPIX = 10 * PITCH;
 
@@ -1012,6 +1017,324 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, CH == 12
 }
 
 // ---------------------------------------------------------------------------------------------
+// tower2s_kernel — tower2b_kernel<T, 256> for batches that leave half the chip idle (BASELINE configs[4] per GPU: 20 x 256
+// at batch 256 = 128 board pairs on 256 CUs).  TWO workgroups per board pair, each computing HALF the output channels
+// (128 of 256) of every layer for both boards; after each layer they exchange their halves of the new image through
+// global memory: write-through (sc1) 16-byte stores, drained, then one relaxed agent-scope flag per workgroup and layer;
+// the partner polls that flag and reads the bytes with sc1 loads (never through its L1; placement-independent — partners
+// are blocks g and g ^ 8, which share an XCD under the usual round-robin placement, but nothing relies on it).
+// The exchange hides behind half a layer: a workgroup walks the reduction OWN channels first (64-channel slices 2h, 2h+1
+// — their activations are already in its LDS), the partner's (2(1-h), 2(1-h)+1) second, and TWO more waves do all of the
+// moving (LDS -> global, flag, poll, global -> LDS) while the four compute waves run the first half.  The price of that
+// order: workgroups with h = 1 sum the slices as 2,3,0,1, so their channels differ in fp32 rounding from
+// tower2b_kernel / the per-layer kernels (which walk 0,1,2,3) — this variant agrees with them to tolerance, not bit for
+// bit (tests/test_gpu_parity.py::test_wide_split_channels_vs_two_board_tower).
+// A wave owns 32 output channels x all 128 pixels (4 accumulators), one weight fragment per k-step global -> registers
+// (tower2b<T,128>'s step); 6 waves on 4 SIMDs, so at most 256 registers (it needs ~190).  Bounded spin: a partner that
+// does not show up within a second raises the policy NaN flag (the call fails) instead of hanging the device; with at most
+// one workgroup per CU and no more workgroups than CUs every partner is resident or becomes so.
+#ifndef KAMI_T2S_NA
+#define KAMI_T2S_NA 12
+#endif
+#ifdef KAMI_WIDE_DIAG
+__device__ unsigned long long g_t2s_stamps[256 * 64 * 8];
+#define T2S_STAMP(l, k) do { if (lane == 0 && blockIdx.x < 256 && (l) < 64) g_t2s_stamps[(blockIdx.x * 64 + (l)) * 8 + (k)] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define T2S_STAMP(l, k) do {} while (0)
+#endif
+struct Tower2sArgs {
+    const float* planes;          // fp32 [B][64][F], F <= 128, 16-byte aligned
+    int F;
+    unsigned magic;               // ceil(2^32 / F)
+    const unsigned short* w;      // tower2b's packing: 72 + 2R x 144 k-steps of 8 KB ([k-step][row tile 0..7][lane][8])
+    const float* shift;           // (1 + 2R) x 256
+    unsigned short* out;          // T [B][64][256]
+    int B, R;
+    unsigned short* xbuf;         // [2 parities][npairs][2 halves][128 pixels][128 channels] T
+    unsigned* xflag;              // [npairs][2] flags, 64 bytes apart; zeroed by the launcher before every launch
+    int* flags;                   // the engine's NaN flags ([0] is raised on an exchange time-out, [3] = 'X')
+    int npairs;
+    int abl;                      // timing-only ablations (KAMI_T2S_ABL): 1 no global exchange, 2 no mover copies at all
+};
+
+template <typename T>
+__global__ __launch_bounds__(384) __attribute__((amdgpu_waves_per_eu(1, 2))) void tower2s_kernel(Tower2sArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    using V = typename Elem<T>::vec8;
+    const int tid = threadIdx.x, lane = tid & 63, h = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    constexpr int CH = 256;
+    constexpr int KSB = CH / 32 * 1024;                     // bytes of one k-step's fragments
+    constexpr int stride = CH * 2 + 16;
+    constexpr int board_bytes = NPIX * stride;
+    const int g = blockIdx.x;
+    const int half = (g >> 3) & 1;
+    const int pair = ((g >> 4) << 3) | (g & 7);             // blocks g and g ^ 8 are the two halves of a pair
+    if (pair >= a.npairs) return;
+    const int b0 = pair * 2;
+    const int NL = 1 + 2 * a.R;
+    const int NKT = 72 + 2 * a.R * 144;
+    char* img = smem;
+    {
+        // the planes of both boards, as tower2b_kernel stages them (both workgroups of a pair read them: the second read
+        // is an L2 hit when they share an XCD); the fifth wave only helps with the zeroes
+        const u32x4 z = { 0, 0, 0, 0 };
+        for (int i = tid; i < 2 * board_bytes / 16; i += 384) *reinterpret_cast<u32x4*>(img + i * 16) = z;
+        const int F = a.F, pieces = 16 * F;
+        constexpr int NU = 16;
+        float4 v[NU];
+        if (wave < 4) {
+#pragma unroll
+            for (int u = 0; u < NU; ++u) {
+                const int i = tid + u * 256;
+                const int bb = __umulhi((unsigned)i, a.magic) >> 4;
+                const int q = i - bb * pieces;
+                v[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (bb < 2 && b0 + bb < a.B) v[u] = *reinterpret_cast<const float4*>(a.planes + ((size_t)(b0 + bb) * 64) * F + 4 * q);
+            }
+        }
+        __syncthreads();
+        if (wave < 4) {
+#pragma unroll
+            for (int u = 0; u < NU; ++u) {
+                const int i = tid + u * 256;
+                const int bb = __umulhi((unsigned)i, a.magic) >> 4;
+                if (bb >= 2) continue;
+                const int q = i - bb * pieces;
+                int p = __umulhi((unsigned)(4 * q), a.magic), c = 4 * q - p * F;
+                const float e[4] = { v[u].x, v[u].y, v[u].z, v[u].w };
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const int pix = ((p >> 3) + 1) * PITCH + (p & 7) + 1;
+                    *reinterpret_cast<unsigned short*>(img + bb * board_bytes + pix * stride + c * 2) = to_bits<T>(e[k]);
+                    if (++c == F) { c = 0; ++p; }
+                }
+            }
+        }
+    }
+    __syncthreads();                                        // the images are staged
+    // layer l's barriers, for all five waves: [X] (l > 0: the partner's half of layer l - 1's output is in the image),
+    // [R] (every wave has read what it needs of the old image), [W] (the own half of the new image is written)
+    if (wave >= 4) {
+        // ---- the two movers, one board each: 16 lanes per pixel (16 x 16 B = the 256 B of one half of a pixel's channels),
+        // 4 pixels per instruction, a board's 16 instructions in flight at once.  Each has a flag of its own and talks to
+        // the partner's mover of the same board (one mover did it in 6-7 us, longer than the half layer it hides behind)
+        const int hw = wave - 4;
+        unsigned* const myflag = a.xflag + (size_t)(pair * 2 + half) * 16 + hw * 8;
+        unsigned* const itsflag = a.xflag + (size_t)(pair * 2 + (half ^ 1)) * 16 + hw * 8;
+        const size_t half_elems = (size_t)128 * 128;
+        const unsigned lane_px = lane >> 4, lane_b = (lane & 15) * 16;
+        auto lds_off = [&](int p, int hh) -> unsigned {     // pixel p = 0..127 of the pair, channels of half hh
+            const int bb = p >> 6, pp = p & 63;
+            return (unsigned)(bb * board_bytes + (((pp >> 3) + 1) * PITCH + (pp & 7) + 1) * stride + hh * 256) + lane_b;
+        };
+        for (int l = 0; l < NL; ++l) {
+            if (l > 0 && !(a.abl & 2)) {
+                // the partner's channels of layer l - 1's output: epoch l in its flag
+                bool ok = true;
+                if (!(a.abl & 1))
+                if (lane == 0) {
+                    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+                    while (__hip_atomic_load(itsflag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned)l) {
+                        __builtin_amdgcn_s_sleep(8);
+                        if (__builtin_amdgcn_s_memrealtime() - t0 > 100000000ull) { ok = false; break; }     // 1 s at 100 MHz
+                    }
+                    if (!ok) { atomicOr(&a.flags[0], 1); a.flags[3] = 'X'; }
+                }
+                if (hw == 0) T2S_STAMP(l, 6);
+                const unsigned short* src = a.xbuf + ((size_t)(((l - 1) & 1) * a.npairs + pair) * 2 + (half ^ 1)) * half_elems;
+                const auto rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(src), 0, (int)(half_elems * 2), 0x00020000);
+                {
+                    // all 32 loads in flight at once (128 registers of this wave's 256): four batches of eight were four
+                    // fabric round trips one after the other — longer than the half layer they have to hide behind
+                    u32x4 r[16];
+#pragma unroll
+                    for (int k = 0; k < 16; ++k) {
+                        const int p = hw * 64 + k * 4 + lane_px;
+                        if (!(a.abl & 1)) r[k] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, p * 256 + lane_b, 0, 16);        // aux 16 = sc1
+                        else r[k] = u32x4{ 0, 0, 0, 0 };
+                        if (a.abl & 4) __builtin_amdgcn_s_sleep(1);      // paced: the compute waves' weight loads go through the same L1
+                    }
+#pragma unroll
+                    for (int k = 0; k < 16; ++k) {
+                        const int p = hw * 64 + k * 4 + lane_px;
+                        *reinterpret_cast<u32x4*>(smem + lds_off(p, half ^ 1)) = r[k];
+                    }
+                }
+            }
+            if (l > 0) {
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                if (hw == 0) T2S_STAMP(l, 7);
+                asm volatile("s_barrier" ::: "memory");                                                      // [X]
+            }
+            asm volatile("s_barrier" ::: "memory");                                                          // [R]
+            asm volatile("s_barrier" ::: "memory");                                                          // [W]
+            if (l + 1 < NL && !(a.abl & 2)) {
+                unsigned short* dst = a.xbuf + ((size_t)((l & 1) * a.npairs + pair) * 2 + half) * half_elems;
+                const auto rsrc = __builtin_amdgcn_make_buffer_rsrc(dst, 0, (int)(half_elems * 2), 0x00020000);
+                {
+                    u32x4 r[16];
+#pragma unroll
+                    for (int k = 0; k < 16; ++k) {
+                        const int p = hw * 64 + k * 4 + lane_px;
+                        r[k] = *reinterpret_cast<const u32x4*>(smem + lds_off(p, half));
+                    }
+#pragma unroll
+                    for (int k = 0; k < 16; ++k) {
+                        const int p = hw * 64 + k * 4 + lane_px;
+                        if (!(a.abl & 1)) __builtin_amdgcn_raw_buffer_store_b128(r[k], rsrc, p * 256 + lane_b, 0, 16);         // write-through
+                        if (a.abl & 4) __builtin_amdgcn_s_sleep(1);
+                    }
+                }
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                             // drained: then the flag
+                if (lane == 0) __hip_atomic_store(myflag, (unsigned)(l + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (hw == 0) T2S_STAMP(l + 1, 5);
+            }
+        }
+        return;
+    }
+    // ---- the four compute waves
+    const int rt = 4 * half + wave;                         // this wave's row tile (32 output channels) of the 8 of a k-step
+    const char* wl = reinterpret_cast<const char*>(a.w) + (size_t)rt * 1024;
+    const unsigned wlane = lane * 16;
+    constexpr int NA = KAMI_T2S_NA;                          // k-steps of weight fragments in flight
+    static_assert(36 % NA == 0, "a slice's first k-step must land on slot 0");
+    V Areg[NA];
+    auto load_a = [&](int slot, int k) {
+        const size_t kc = (size_t)(k < NKT ? k : NKT - 1) * KSB;         // past the end: a harmless re-read
+        unsigned vo = wlane;
+        asm volatile("" : "+v"(vo));
+        Areg[slot] = *reinterpret_cast<const V*>(wl + kc + vo);
+    };
+#pragma unroll
+    for (int j = 0; j < NA; ++j) load_a(j, j);
+    const int lp = PIXMAP[lane & 31];
+    const int py = lp >> 3, px = lp & 7;
+    const unsigned b_base = (py * PITCH + px) * stride + h * 16;
+    auto tile_off = [](int pt) -> unsigned { return (unsigned)((pt >> 1) * board_bytes + (pt & 1) * 4 * PITCH * stride); };
+    char* const w_base = smem + ((py + 1) * PITCH + px + 1) * stride + (32 * rt + 4 * h) * 2;
+    f32x16 acc[4];
+    auto load_shift = [&](int l) {
+        const int lc = l < NL ? l : NL - 1;
+#pragma unroll
+        for (int gq = 0; gq < 4; ++gq) {
+            const float4 s4 = *reinterpret_cast<const float4*>(a.shift + lc * CH + 32 * rt + 8 * gq + 4 * h);
+#pragma unroll
+            for (int pt = 0; pt < 4; ++pt) {
+                acc[pt][4 * gq + 0] = s4.x; acc[pt][4 * gq + 1] = s4.y;
+                acc[pt][4 * gq + 2] = s4.z; acc[pt][4 * gq + 3] = s4.w;
+            }
+        }
+    };
+    load_shift(0);
+    auto kstep_off = [](int n) -> unsigned {
+        const int tap = n >> 2, kk = n & 3;
+        return (unsigned)(((tap / 3) * PITCH + (tap % 3)) * stride) + kk * 32;
+    };
+    constexpr int NBS = 3;                                   // activation fragments two k-steps ahead
+    V Bq[NBS][4];
+    unsigned xr[4][4][2];                                    // the residual stream of this lane's outputs, packed T
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int gq = 0; gq < 4; ++gq) xr[i][gq][0] = xr[i][gq][1] = 0;
+    // 36 k-steps of activation slice `q` (weights: k-steps kcur ..; the fragments requested past the slice's end are the
+    // NEXT slice of this workgroup's walk: knext / qnext)
+    auto slice_steps = [&](int kcur, int knext, int q, int qnext) {
+#pragma unroll
+        for (int n = 0; n < 36; ++n) {
+            const int cur = n % NBS, nxt = (n + NBS - 1) % NBS, slot = n % NA;                  // 36 % NA == 0: a slice starts on slot 0
+            const int m = n + NBS - 1;
+            const unsigned off = m < 36 ? kstep_off(m) + q * 128 : kstep_off(m - 36) + qnext * 128;
+            __builtin_amdgcn_sched_barrier(0);               // a step's loads stay in their step
+#pragma unroll
+            for (int pt = 0; pt < 4; ++pt) Bq[nxt][pt] = *reinterpret_cast<const V*>(smem + b_base + tile_off(pt) + off);
+#pragma unroll
+            for (int pt = 0; pt < 4; ++pt) acc[pt] = Elem<T>::mfma(Areg[slot], Bq[cur][pt], acc[pt]);
+            load_a(slot, n + NA < 36 ? kcur + n + NA : knext + n + NA - 36);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            }
+            __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+        }
+    };
+    auto preload_b = [&](int q) {
+#pragma unroll
+        for (int j = 0; j < NBS - 1; ++j)
+#pragma unroll
+            for (int pt = 0; pt < 4; ++pt) Bq[j][pt] = *reinterpret_cast<const V*>(smem + b_base + tile_off(pt) + kstep_off(j) + q * 128);
+    };
+    auto boundary = [&](auto kind) {
+        constexpr int KIND = decltype(kind)::value;
+#pragma unroll
+        for (int pt = 0; pt < 4; ++pt)
+#pragma unroll
+            for (int gq = 0; gq < 4; ++gq) {
+                float v[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) v[i] = relu_keep_nan(acc[pt][4 * gq + i]);
+                if (KIND == 2) {
+                    const unsigned s0 = xr[pt][gq][0], s1 = xr[pt][gq][1];
+                    v[0] += from_bits<T>((unsigned short)(s0 & 0xffff)); v[1] += from_bits<T>((unsigned short)(s0 >> 16));
+                    v[2] += from_bits<T>((unsigned short)(s1 & 0xffff)); v[3] += from_bits<T>((unsigned short)(s1 >> 16));
+                }
+                const unsigned p0 = pack2<T>(v[0], v[1]), p1 = pack2<T>(v[2], v[3]);
+                if (KIND != 1) { xr[pt][gq][0] = p0; xr[pt][gq][1] = p1; }
+                *reinterpret_cast<u32x2*>(w_base + tile_off(pt) + (8 * gq) * 2) = u32x2{ p0, p1 };
+            }
+    };
+    // slice i of this workgroup's walk through a tower layer -> the 64-channel slice it is: own channels first
+    // (ONE call site of slice_steps inside a loop, as in tower2b_kernel: with the four slices written out one after the
+    //  other hipcc sank every prefetched fragment down to its use — load, wait, MFMA, 3.8x the time)
+    const int sx = 2 * half;
+    auto slice_of = [&](int l, int i) -> int { return l == 0 ? i : (i ^ sx); };
+    auto kbase_of = [&](int l) -> int { return l == 0 ? 0 : 72 + (l - 1) * 144; };
+    for (int l = 0; l < NL; ++l) {
+        const int ns = l == 0 ? 2 : 4;
+        if (wave == 0) T2S_STAMP(l, 0);
+        preload_b(slice_of(l, 0));
+        for (int i = 0; i < ns; ++i) {
+            if (l > 0 && i == 2) {
+                if (wave == 0) T2S_STAMP(l, 1);
+                asm volatile("s_barrier" ::: "memory");                                   // [X]
+                if (wave == 0) T2S_STAMP(l, 2);
+                preload_b(slice_of(l, 2));                   // (what the previous slice prefetched here was not the partner's yet)
+            }
+            const int q = slice_of(l, i);
+            const bool last = i + 1 == ns;
+            const int qn = last ? slice_of(l + 1, 0) : slice_of(l, i + 1);
+            const int kcur = kbase_of(l) + q * 36, knext = (last ? kbase_of(l + 1) : kbase_of(l)) + qn * 36;
+            slice_steps(kcur, knext, q, qn);
+        }
+        if (wave == 0) T2S_STAMP(l, 3);
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");                   // [R]
+        if (l == 0) boundary(std::integral_constant<int, 0>{});
+        else if (l & 1) boundary(std::integral_constant<int, 1>{});
+        else boundary(std::integral_constant<int, 2>{});
+        load_shift(l + 1);
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");                   // [W]
+        if (wave == 0) T2S_STAMP(l, 4);
+    }
+#pragma unroll
+    for (int pt = 0; pt < 4; ++pt) {
+        const int b = b0 + (pt >> 1);
+        if (b >= a.B) continue;
+        const int pix = (4 * (pt & 1) + py) * 8 + px;
+        const size_t row = ((size_t)b * 64 + pix) * CH + 32 * rt;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const auto s0 = __builtin_amdgcn_permlane32_swap(xr[pt][2 * j][0], xr[pt][2 * j + 1][0], false, false);
+            const auto s1 = __builtin_amdgcn_permlane32_swap(xr[pt][2 * j][1], xr[pt][2 * j + 1][1], false, false);
+            const u32x4 o = { s0[0], s1[0], s0[1], s1[1] };
+            *reinterpret_cast<u32x4*>(a.out + row + 16 * j + 8 * h) = o;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // policy_head4_kernel — the whole policy head (nn.cpp:72-80) of four boards per workgroup in one launch:
 // policyconv 1x1 (C -> 128) + pbatchnorm + ReLU, policyconv2 1x1 (128 -> 73) + bias, softmax over the board's 4 672
 // logits, policy row out.  conv4's tiling again: a wave owns one board and all output channels, so the 128-channel
@@ -1760,8 +2083,14 @@ template <typename T> static hipError_t run(const LayersArgs& L, hipStream_t s)
     // It reads the fp32 planes itself: ONE condition decides both that and whether planes_to_act_kernel runs (they used to
     // disagree for 256 filters at 256 <= batch < 384: a launch whose output nobody read).
     const bool aligned = (reinterpret_cast<uintptr_t>(L.in) & 15) == 0;
-    const bool fused256 = aligned && L.FP == 128 && ((L.CP == 256 && L.w2b && (force == 6 || (!force && L.B >= 256))) ||
-                                                      (L.CP == 128 && L.w4 && L.w4_off[0] != (size_t)-1 && (force == 6 || (!force && L.B >= 256 && !fused))));
+    // 256 filters, up to one board pair per TWO CUs: two workgroups per pair, each half the output channels, halves
+    // exchanged per layer (tower2s_kernel; KAMI_WIDE_VARIANT=7 forces it, 6 keeps tower2b_kernel).  Every workgroup must
+    // be resident (partners wait for each other): never more workgroups than CUs.
+    const int pairs = (L.B + 1) / 2, grid2s = 16 * ((pairs + 7) / 8);
+    const bool split = aligned && L.FP == 128 && L.CP == 256 && L.w2b && L.xbuf && L.xflag && pairs <= L.x_pairs && grid2s <= L.num_cus &&
+                       (force == 7 || (!force && L.B >= KAMI_SPLIT_MIN_B));
+    const bool fused256 = split || (aligned && L.FP == 128 && ((L.CP == 256 && L.w2b && (force == 6 || (!force && L.B >= 256))) ||
+                                                                (L.CP == 128 && L.w4 && L.w4_off[0] != (size_t)-1 && (force == 6 || (!force && L.B >= 256 && !fused)))));
     if (!direct && !fused256) hipLaunchKernelGGL(planes_to_act_kernel<T>, dim3(blocks), dim3(256), 0, s, L.in, L.act_in, npix, L.F, L.FP);
     unsigned short *x = L.act[0], *t = L.act[1], *u = L.act[2];
     hipError_t e;
@@ -1778,12 +2107,30 @@ template <typename T> static hipError_t run(const LayersArgs& L, hipStream_t s)
             if ((e = hipFuncSetAttribute(reinterpret_cast<const void*>(&tower2b_kernel<T, 128>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)) != hipSuccess) return e;
             attr_done.store(true, std::memory_order_release);
         }
+        if (split) {
+            static std::atomic<bool> attr2s_done{ false };
+            if (!attr2s_done.load(std::memory_order_acquire)) {
+                if ((e = hipFuncSetAttribute(reinterpret_cast<const void*>(&tower2s_kernel<T>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)) != hipSuccess) return e;
+                attr2s_done.store(true, std::memory_order_release);
+            }
+            // every polled word zero before every launch (a block of its own at the allocation's start, a multiple of 16 bytes)
+            if ((e = hipMemsetAsync(L.xflag, 0, layers_xflag_bytes(pairs), s)) != hipSuccess) return e;
+            Tower2sArgs t2;
+            t2.planes = L.in; t2.F = L.F; t2.magic = (unsigned)((0x100000000ull + L.F - 1) / L.F);
+            t2.w = L.w2b; t2.shift = shift(0); t2.out = x; t2.B = L.B; t2.R = L.R;
+            t2.xbuf = L.xbuf; t2.xflag = L.xflag; t2.flags = L.flags; t2.npairs = pairs;
+            static const int abl2s = getenv("KAMI_T2S_ABL") ? atoi(getenv("KAMI_T2S_ABL")) : 0;
+            t2.abl = abl2s;
+            hipLaunchKernelGGL((tower2s_kernel<T>), dim3(grid2s), dim3(384), 2 * NPIX * (256 * 2 + 16), s, t2);
+            if ((e = hipGetLastError()) != hipSuccess) return e;
+        } else {
         Tower256Args t2;
         t2.planes = L.in; t2.F = L.F; t2.magic = (unsigned)((0x100000000ull + L.F - 1) / L.F);
         t2.w = L.CP == 256 ? L.w2b : layer4(0); t2.shift = shift(0); t2.out = x; t2.B = L.B; t2.R = L.R;
         if (L.CP == 256) hipLaunchKernelGGL((tower2b_kernel<T, 256>), dim3((L.B + 1) / 2), dim3(256), 2 * NPIX * (256 * 2 + 16), s, t2);
         else hipLaunchKernelGGL((tower2b_kernel<T, 128>), dim3((L.B + 1) / 2), dim3(256), 2 * NPIX * (128 * 2 + 16), s, t2);
         if ((e = hipGetLastError()) != hipSuccess) return e;
+        }
         li = 1 + 2 * (size_t)L.R;
     }
     if (fused && !fused256) {
@@ -1851,6 +2198,10 @@ template <typename T> static hipError_t run(const LayersArgs& L, hipStream_t s)
 extern "C" int kh_debug_t128_stamps(unsigned long long* out, int n)
 {
     return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(lay::g_t128_stamps), (size_t)n * 8, 0, hipMemcpyDeviceToHost);
+}
+extern "C" int kh_debug_t2s_stamps(unsigned long long* out, int n)
+{
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(lay::g_t2s_stamps), (size_t)n * 8, 0, hipMemcpyDeviceToHost);
 }
 extern "C" int kh_debug_wide_stamps(unsigned long long* out, int n)
 {

@@ -204,20 +204,33 @@ def test_forward_wide_nets_vs_oracle(dtype, F, C, R, B):
 
 
 @pytest.mark.parametrize("dtype", ["bf16", "f16"])
-@pytest.mark.parametrize("C,B,step", [(128, 513, 100), (128, 1024, 100), (128, 1021, 255), (256, 200, 50), (256, 131, 50), (256, 515, 103)])
+@pytest.mark.parametrize("C,B,step", [(128, 513, 100), (128, 1024, 100), (128, 1021, 255), (256, 200, 50), (256, 131, 50), (256, 600, 300), (256, 515, 103)])
 def test_wide_two_workgroups_per_cu_variant_matches(dtype, C, B, step):
     """Wide nets: the launcher picks the 3x3 layer kernel per call — one workgroup per CU with a 4-slot ring (small
     batches), two or three per CU with a 2-slot ring and passes of 128 / 64 input channels, and from 256 workgroups of
     FOUR boards x 128 output channels on conv4_mfma_kernel (128 channels: batch >= 1021; 256 channels: batch >= 509).
     All of them walk the reduction in the same order with the same fp32 epilogue: the same boards evaluated `step`
-    at a time (another variant) must give the same bits, ragged last groups included."""
+    at a time (another variant) must give the same bits, ragged last groups included.
+    256 filters since round 3: batches up to 256 run tower2s_kernel (two workgroups per board pair, each half the
+    output channels; channels >= 128 sum their 64-channel slices in the order 2,3,0,1), larger ones tower2b_kernel
+    (0,1,2,3): bit-identical within each range ((200, 50), (131, 50), (600, 300)), equal to rounding across the two
+    ((515, 103): observed 1.2e-2 on logits / 7e-4 on probabilities / 7e-4 on values in f16 at TWENTY blocks, 8.9e-2 /
+    3.9e-3 / 4.8e-3 in bf16 — tools/split_check.py; both ranges are pinned against the oracle at full depth by
+    test_full_size_properties_wide_configs)."""
     F, R = 119, 2
     nn = NN(8, 8, F, 4672, filters=C, residuals=R, dtype=dtype)
     nn.load_weights(W.random_weights(F, C, R, seed=77, peaky=10.0), 1)
     x = np.random.default_rng(B).random((B, 8, 8, F), dtype=np.float32)
     p, vf, lg = nn.infer_full(x)
+    across = C == 256 and B > 256 >= step
+    tl, tp, tv = (1e-1, 5e-3, 6e-3) if dtype == "bf16" else (1.5e-2, 1e-3, 1e-3)
     for lo in range(0, B, step):
         pp, pv, pl = nn.infer_full(x[lo:lo + step])
+        if across:
+            np.testing.assert_allclose(lg[lo:lo + step], pl, atol=tl, rtol=0)
+            np.testing.assert_allclose(p[lo:lo + step], pp, atol=tp, rtol=0)
+            np.testing.assert_allclose(vf[lo:lo + step], pv, atol=tv, rtol=0)
+            continue
         np.testing.assert_array_equal(lg[lo:lo + step], pl)
         np.testing.assert_array_equal(p[lo:lo + step], pp)
         np.testing.assert_array_equal(vf[lo:lo + step], pv)

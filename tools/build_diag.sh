@@ -6,5 +6,5 @@ set -e
 cd "$(dirname "$0")/../kami_amd/csrc"
 RT=$(python3 -c 'import os,torch;print(os.path.join(os.path.dirname(torch.__file__),"lib"))' 2>/dev/null || echo /opt/rocm/lib)
 hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -Wall -Wno-unused-result -Wno-pass-failed -ffp-contract=fast -DKAMI_WIDE_DIAG -c layers_mfma.hip -o build/layers_mfma_diag.o
-g++ -shared -o build/libkamihip_diag.so build/kh_api.o build/encode.o build/forward_simple.o build/tower_mfma.o build/layers_mfma_diag.o build/train.o -L$RT -lamdhip64 -Wl,-rpath,$RT -lpthread
+g++ -shared -o build/libkamihip_diag.so build/kh_api.o build/encode.o build/forward_simple.o build/tower_mfma.o build/tower8_mfma.o build/layers_mfma_diag.o build/train.o -L$RT -lamdhip64 -Wl,-rpath,$RT -lpthread
 ls -la build/libkamihip_diag.so
