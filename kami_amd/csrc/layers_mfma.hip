@@ -36,6 +36,12 @@ using u32x4 = __attribute__((ext_vector_type(4))) unsigned;
 using u32x2 = __attribute__((ext_vector_type(2))) unsigned;
 using f32x4s = __attribute__((ext_vector_type(4))) float;
 
+#ifndef KAMI_T2B_NA
+#define KAMI_T2B_NA 12           // tower2b_kernel: k-steps of weight fragments in flight (4 -> 12: 10x128 at batch 512 198 -> 186 us, 20x256 +0.5 %)
+#endif
+#ifndef KAMI_T2S_NA
+#define KAMI_T2S_NA 12           // tower2s_kernel: the same (4: 653 us, 6: 626, 9: 623, 12: 620 at 20x256 batch 256: the movers' sc1 traffic delays the L2)
+#endif
 #ifndef KAMI_SPLIT_MIN_B
 #define KAMI_SPLIT_MIN_B 1           // 256 filters: smallest batch on tower2s_kernel (against the per-layer kernels, 20x256 f16: 439 vs 480 us at
                                     // batch 1, 449 vs 499 at 32, 456 vs 564 at 128, 641 vs 972 at 254: it wins everywhere, so one kernel family — one
@@ -845,7 +851,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, CH == 12
     const char* wl = reinterpret_cast<const char*>(a.w) + (size_t)(MSW * wave) * 1024;
     const unsigned wlane = lane * 16;
     // requested NA k-steps ahead: 4 x 256 clocks of MFMAs at 256 channels, 8 x 128 at 128 — an L2 round trip under load
-    constexpr int NA = 4;                                    // k-steps of weight fragments in flight (8 bought nothing at 128 channels and cost the second workgroup per CU its registers)
+    constexpr int NA = KAMI_T2B_NA;                          // k-steps of weight fragments in flight (8 bought nothing at 128 channels and cost the second workgroup per CU its registers)
     V Areg[NA][MSW];
     auto load_a = [&](int slot, int k) {
         const size_t kc = (size_t)(k < NKT ? k : NKT - 1) * KSB;         // past the end: a harmless re-read
@@ -932,7 +938,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, CH == 12
         constexpr int S0 = decltype(s0)::value;
 #pragma unroll
         for (int n = 0; n < 36; ++n) {
-            const int cur = n % NBS, nxt = (n + NBS - 1) % NBS, slot = (n + S0) & (NA - 1);
+            const int cur = n % NBS, nxt = (n + NBS - 1) % NBS, slot = (n + S0) % NA;
             // activations of k-step n + NBS - 1 (past the slice's end: the next slice's first — or, at a layer's end, a
             // harmless address: the layer start re-reads after the boundary's barriers)
             const int m = n + NBS - 1;
@@ -983,7 +989,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, CH == 12
             for (int pt = 0; pt < 4; ++pt) Bq[j][pt] = *reinterpret_cast<const V*>(smem + b_base + tile_off(pt) + kstep_off(j));
         const int nslice = l == 0 ? 2 : NSL;                // the stem's 128 (padded) planes, the tower's CH channels
         for (int q = 0; q < nslice; ++q) {
-            if constexpr (NA == 4) slice_steps(k0, q, std::integral_constant<int, 0>{});
+            if constexpr (36 % NA == 0) slice_steps(k0, q, std::integral_constant<int, 0>{});
             else if ((k0 & 7) == 0) slice_steps(k0, q, std::integral_constant<int, 0>{});
             else slice_steps(k0, q, std::integral_constant<int, 4>{});
             k0 += 36;
@@ -1033,9 +1039,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, CH == 12
 // (tower2b<T,128>'s step); 6 waves on 4 SIMDs, so at most 256 registers (it needs ~190).  Bounded spin: a partner that
 // does not show up within a second raises the policy NaN flag (the call fails) instead of hanging the device; with at most
 // one workgroup per CU and no more workgroups than CUs every partner is resident or becomes so.
-#ifndef KAMI_T2S_NA
-#define KAMI_T2S_NA 12
-#endif
 #ifdef KAMI_WIDE_DIAG
 __device__ unsigned long long g_t2s_stamps[256 * 64 * 8];
 #define T2S_STAMP(l, k) do { if (lane == 0 && blockIdx.x < 256 && (l) < 64) g_t2s_stamps[(blockIdx.x * 64 + (l)) * 8 + (k)] = __builtin_amdgcn_s_memtime(); } while (0)
@@ -2091,6 +2094,9 @@ template <typename T> static hipError_t run(const LayersArgs& L, hipStream_t s)
                        (force == 7 || (!force && L.B >= KAMI_SPLIT_MIN_B));
     const bool fused256 = split || (aligned && L.FP == 128 && ((L.CP == 256 && L.w2b && (force == 6 || (!force && L.B >= 256))) ||
                                                                 (L.CP == 128 && L.w4 && L.w4_off[0] != (size_t)-1 && (force == 6 || (!force && L.B >= 256 && !fused)))));
+    static const bool dbg = getenv("KAMI_WIDE_DEBUG") != nullptr;
+    if (dbg) fprintf(stderr, "[kami wide] B %d FP %d CP %d aligned %d w2b %d xbuf %d x_pairs %d num_cus %d grid2s %d force %d -> split %d fused256 %d fused %d\n",
+                     L.B, L.FP, L.CP, (int)aligned, L.w2b != nullptr, L.xbuf != nullptr, L.x_pairs, L.num_cus, grid2s, force, (int)split, (int)fused256, (int)fused);
     if (!direct && !fused256) hipLaunchKernelGGL(planes_to_act_kernel<T>, dim3(blocks), dim3(256), 0, s, L.in, L.act_in, npix, L.F, L.FP);
     unsigned short *x = L.act[0], *t = L.act[1], *u = L.act[2];
     hipError_t e;

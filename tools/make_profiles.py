@@ -118,12 +118,12 @@ for Cc, Rr, B, dt in ((128, 10, 1024, "bf16"), (256, 20, 256, "f16"), (256, 20, 
         continue
     write_stats(rows, f"{tag}_wide_{Rr}x{Cc}_b{B}_{dt}_kernel_stats.csv")
     dominant = max(rows, key=lambda r: float(r["TotalDurationNs"]))
-    key = next((k for k in ("tower128_kernel", "tower2b_kernel", "conv4_mfma_kernel") if k in dominant["Name"]), "conv_mfma_kernel")
+    key = next((k for k in ("tower128_kernel", "tower2b_kernel", "tower2s_kernel", "conv4_mfma_kernel") if k in dominant["Name"]), "conv_mfma_kernel")
     ctr = {}
     for d in (f"pmcf_{wtag}", f"pmcw_{wtag}", f"pmcs_{wtag}"):
         ctr.update(counters(d, key))
     calls = {r["Name"]: int(r["Calls"]) for r in rows}
-    once = [int(r["Calls"]) for r in rows if any(k in r["Name"] for k in ("policy_head4", "softmax", "tower128", "tower2b"))]
+    once = [int(r["Calls"]) for r in rows if any(k in r["Name"] for k in ("policy_head4", "softmax", "tower128", "tower2b", "tower2s"))]
     fwd = min(once) if once else 1                         # kernels that run once per forward
     per_forward_ns = sum(float(r["TotalDurationNs"]) for r in rows if "fillBuffer" not in r["Name"] and "copyBuffer" not in r["Name"]) / fwd
     flops = (1152 * 119 * Cc + 2304 * Rr * Cc * Cc + 16512 * Cc + 1228800) * B
@@ -134,9 +134,15 @@ for Cc, Rr, B, dt in ((128, 10, 1024, "bf16"), (256, 20, 256, "f16"), (256, 20, 
                                  "share_of_kernel_time": float(dominant["TotalDurationNs"]) / sum(float(r["TotalDurationNs"]) for r in rows)},
              "counters_of_dominant_kernel_per_dispatch": ctr}
     # algorithmic HBM bytes of the dominant kernel's dispatch
-    if key in ("tower128_kernel", "tower2b_kernel"):
+    if key in ("tower128_kernel", "tower2b_kernel", "tower2s_kernel"):
         # fp32 planes in, residual stream out (T), every layer's packed weights once
         alg = B * 64 * 119 * 4 + B * 64 * Cc * 2 + (9 * 128 * Cc + Rr * 2 * 9 * Cc * Cc) * 2
+        if key == "tower2s_kernel":
+            # its own design adds: the planes read by both workgroups of a pair, and per layer but the last every board's
+            # new image written once and read once through the exchange area
+            entry["exchange_bytes_per_launch"] = 2 * Rr * 2 * B * 64 * Cc * 2
+            entry["note"] = ("two workgroups per board pair exchange half an image per layer through global memory (sc1 stores, sc1 loads): "
+                             "that traffic is the kernel's design, on top of the algorithmic bytes")
     elif key == "conv4_mfma_kernel":
         alg = B * 64 * Cc * 2 * 3                               # in, skip, out
     else:
