@@ -36,6 +36,9 @@ using u32x4 = __attribute__((ext_vector_type(4))) unsigned;
 using u32x2 = __attribute__((ext_vector_type(2))) unsigned;
 using f32x4s = __attribute__((ext_vector_type(4))) float;
 
+#ifndef KAMI_WIDE_BUFA
+#define KAMI_WIDE_BUFA 1           // tower2b / tower2s weight fragments by buffer loads (0: global loads, the A/B baseline)
+#endif
 #ifndef KAMI_T2B_NA
 #define KAMI_T2B_NA 12           // tower2b_kernel: k-steps of weight fragments in flight (4 -> 12: 10x128 at batch 512 198 -> 186 us, 20x256 +0.5 %)
 #endif
@@ -853,6 +856,18 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, CH == 12
     // requested NA k-steps ahead: 4 x 256 clocks of MFMAs at 256 channels, 8 x 128 at 128 — an L2 round trip under load
     constexpr int NA = KAMI_T2B_NA;                          // k-steps of weight fragments in flight (8 bought nothing at 128 channels and cost the second workgroup per CU its registers)
     V Areg[NA][MSW];
+#if KAMI_WIDE_BUFA
+    // buffer loads: descriptor in SGPRs, the k-step's byte offset in ONE SGPR, the lane offset a loop-invariant VGPR — one
+    // scalar add and the load per k-step (the global_load form cost seven scalar instructions and a v_mov per step, and a
+    // 4-MFMA step is issue-bound with one wave per SIMD: 20x256 batch 256 with the weight loads removed 622 -> 487 us).
+    // Past the stack's end the range check returns zeros: no clamp.
+    const auto a_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(wl), 0, NKT * KSB - MSW * wave * 1024, 0x00020000);
+    auto load_a = [&](int slot, int k) {
+#pragma unroll
+        for (int ms = 0; ms < MSW; ++ms)
+            Areg[slot][ms] = __builtin_bit_cast(V, __builtin_amdgcn_raw_buffer_load_b128(a_rsrc, wlane + ms * 1024, k * KSB, 0));
+    };
+#else
     auto load_a = [&](int slot, int k) {
         const size_t kc = (size_t)(k < NKT ? k : NKT - 1) * KSB;         // past the end: a harmless re-read
         unsigned vo = wlane;
@@ -860,6 +875,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, CH == 12
 #pragma unroll
         for (int ms = 0; ms < MSW; ++ms) Areg[slot][ms] = *reinterpret_cast<const V*>(wl + kc + ms * 1024 + vo);
     };
+#endif
 #pragma unroll
     for (int j = 0; j < NA; ++j) load_a(j, j);
     {
@@ -1204,12 +1220,19 @@ __global__ __launch_bounds__(384) __attribute__((amdgpu_waves_per_eu(1, 2))) voi
     constexpr int NA = KAMI_T2S_NA;                          // k-steps of weight fragments in flight
     static_assert(36 % NA == 0, "a slice's first k-step must land on slot 0");
     V Areg[NA];
+#if KAMI_WIDE_BUFA
+    const auto a_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(wl), 0, NKT * KSB - rt * 1024, 0x00020000);   // (see tower2b_kernel)
+    auto load_a = [&](int slot, int k) {
+        Areg[slot] = __builtin_bit_cast(V, __builtin_amdgcn_raw_buffer_load_b128(a_rsrc, wlane, k * KSB, 0));
+    };
+#else
     auto load_a = [&](int slot, int k) {
         const size_t kc = (size_t)(k < NKT ? k : NKT - 1) * KSB;         // past the end: a harmless re-read
         unsigned vo = wlane;
         asm volatile("" : "+v"(vo));
         Areg[slot] = *reinterpret_cast<const V*>(wl + kc + vo);
     };
+#endif
 #pragma unroll
     for (int j = 0; j < NA; ++j) load_a(j, j);
     const int lp = PIXMAP[lane & 31];
@@ -1251,11 +1274,15 @@ __global__ __launch_bounds__(384) __attribute__((amdgpu_waves_per_eu(1, 2))) voi
             const int m = n + NBS - 1;
             const unsigned off = m < 36 ? kstep_off(m) + q * 128 : kstep_off(m - 36) + qnext * 128;
             __builtin_amdgcn_sched_barrier(0);               // a step's loads stay in their step
+#if !defined(KAMI_T2S_NOB)
 #pragma unroll
             for (int pt = 0; pt < 4; ++pt) Bq[nxt][pt] = *reinterpret_cast<const V*>(smem + b_base + tile_off(pt) + off);
+#endif
 #pragma unroll
             for (int pt = 0; pt < 4; ++pt) acc[pt] = Elem<T>::mfma(Areg[slot], Bq[cur][pt], acc[pt]);
+#if !defined(KAMI_T2S_NOA)
             load_a(slot, n + NA < 36 ? kcur + n + NA : knext + n + NA - 36);
+#endif
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
