@@ -998,12 +998,14 @@ constexpr int CO_SMALL_LEGAL = 512;             // a submission larger than this
 constexpr int CO_SMALL_PLANES = 128;
 constexpr int CO_BUFFERS = 12;                  // up to max_inflight on the device, one filling, the rest waiting for their callers to fetch
 
-// The queue's lock.  Its critical sections are a few hundred nanoseconds (reserve rows, scan six batches) and a dozen
+// The queue's lock.  Its critical sections are a few hundred nanoseconds (reserve rows, look at the batches) and a dozen
 // workers hit it within the same microsecond when a launch hands their tickets back: with std::mutex the losers sleep
 // on the futex and are woken one after the other (2-3 us each: measured as 33-37 us of "filling" per launch with 14
 // workers), so it spins.  Sleeping paths (idle lane, buffers all on the device, waiters past their spin time) go
 // through std::condition_variable_any, which takes any lock type.
 struct SpinLock {
+    // test-and-test-and-set.  (A ticket lock — FIFO hand-over, waiters on a plain load — was measured: the same with two sets
+    // per worker, worse with four: 3.3-3.5 -> 2.8-3.0 M/s; a FIFO queue turns one descheduled waiter into everybody's wait.)
     std::atomic<int> held{ 0 };
     void lock()
     {
@@ -1019,11 +1021,14 @@ struct SpinLock {
     void unlock() { held.store(0, std::memory_order_release); }
 };
 
-struct CoTicket {
-    uint32_t serial = 0;
-    std::atomic<int> state{ 0 };                // 0 free, 1 queued, 2 done: results in the caller's buffers (waiters spin on it, then
+// (A waiter polls `state` in a tight loop, the dispatcher writes the other fields right before it publishes: the polled word
+//  has a cache line of its own, and no two tickets share one — a dozen pollers on the lines the dispatcher was writing made
+//  its hand-back 10-18 us per launch with three sets per worker.)
+struct alignas(64) CoTicket {
+    alignas(64) std::atomic<int> state{ 0 };    // 0 free, 1 queued, 2 done: results in the caller's buffers (waiters spin on it, then
                                                 // sleep), 4 results in the batch's page-locked block, 5 somebody is copying them out
-    struct CoBatch* from = nullptr;             // state 4 / 5: the batch that holds this ticket's rows
+    uint32_t serial = 0;                        // (same line as `state`: written at submit time only, read by every poll)
+    alignas(64) struct CoBatch* from = nullptr; // state 4 / 5: the batch that holds this ticket's rows
     int status = KH_OK;
     std::string err;
     int kind = 0, row0 = 0, rows = 0, act0 = 0, nact = 0;
@@ -1065,6 +1070,11 @@ struct Coalescer {
     std::condition_variable_any cv_lane, cv_done, cv_space;
     CoTicket tickets[KH_MAX_OUTSTANDING];
     CoBatch batches[CO_BUFFERS];
+    std::atomic<uint64_t> free_mask{ ~0ull };   // bit i: ticket i is free (a submit takes the lowest under mu, a wait gives its own
+                                                // back without the lock); KH_MAX_OUTSTANDING == 64 == its width
+    std::atomic<unsigned> submits{ 0 };         // bumped by every submission: the dispatcher scans the batches (under mu) only when
+                                                // it has changed, a deadline is due or a launch slot has come back
+    std::atomic<bool> asleep{ false };          // the dispatcher sleeps on cv_lane: only then does a submitter notify it
     std::thread dispatcher;
     // Launches on the device at once: each on a lane = a stream of its own + device scratch.  FOUR streams, created one
     // after the other, because that is how many hardware queues the runtime spreads streams over: with a stream per
@@ -1266,16 +1276,27 @@ void co_dispatch(Coalescer* c)
             c->us_run += us(t_ran - b->t_run); c->us_finish += us(std::chrono::steady_clock::now() - t_ran);
         }
     };
+    // The batches are looked at (under the queue's lock) only when something can have changed: a submission since the last
+    // look, a deadline of an open batch, a launch slot that has come back, a settings change / stop (they bump `submits`
+    // too).  Looking every time round made the dispatcher the 15th contender for a lock 14 workers submit through.
+    unsigned seen = c->submits.load(std::memory_order_acquire) - 1;
+    bool open_any = false, slot_back = false;
+    auto next_due = std::chrono::steady_clock::time_point::max();
     for (unsigned spin = 0;; ++spin) {
         CoBatch* take = nullptr;
-        {
+        const unsigned subs = c->submits.load(std::memory_order_acquire);
+        if (subs != seen || slot_back || (open_any && std::chrono::steady_clock::now() >= next_due) ||
+            (!open_any && nfly == 0 && ndrain == 0)) {
             std::unique_lock<SpinLock> lk(c->mu);
-            bool open_any = false;
+            seen = c->submits.load(std::memory_order_acquire);
+            slot_back = false;
+            open_any = false;
+            next_due = std::chrono::steady_clock::time_point::max();
             const int target = e->co_target.load(), wait_us = e->co_wait_us.load(), callers = e->co_callers.load();
             for (auto& b : c->batches) {
                 if (b.state != 1 || b.rows == 0) continue;
                 open_any = true;
-                if (nfly >= c->max_inflight) break;
+                if (nfly >= c->max_inflight) { next_due = std::chrono::steady_clock::time_point::max(); break; }   // (a slot coming back re-opens the question)
                 // immediate mode (no target): whatever has accumulated goes at once;
                 // target mode: wait for `target` rows or `callers` submissions — but no longer than wait_us after the
                 // batch's first submission, and not once the burst of submissions has ended (nothing added for
@@ -1285,15 +1306,19 @@ void co_dispatch(Coalescer* c)
                 if (!ready) {
                     const auto due = std::min(b.first + std::chrono::microseconds(wait_us), b.last + std::chrono::microseconds(wait_us / 8 + 1));
                     ready = std::chrono::steady_clock::now() >= due;
+                    if (!ready) next_due = std::min(next_due, due);
                 }
                 if (ready) { take = &b; break; }
             }
             if (!take && !open_any && nfly == 0 && ndrain == 0) {
                 if (c->stop) return;
+                c->asleep.store(true, std::memory_order_release);
                 c->cv_lane.wait(lk);                 // nothing queued, nothing on the device
+                c->asleep.store(false, std::memory_order_release);
+                seen = c->submits.load(std::memory_order_acquire) - 1;
                 continue;
             }
-            if (take) { take->state = 2; take->t_seal = std::chrono::steady_clock::now(); }
+            if (take) { take->state = 2; take->t_seal = std::chrono::steady_clock::now(); seen = subs - 1; }   // (look again: another batch may be ready)
         }
         if (take) {
             while (take->copying.load(std::memory_order_acquire) > 0) __builtin_ia32_pause();   // submitters still copying their rows in: a microsecond
@@ -1322,6 +1347,7 @@ void co_dispatch(Coalescer* c)
             c->lane_busy[b->lane - c->lanes] = false;
             complete(b, rc, true);
             fly[i] = fly[--nfly];
+            slot_back = true;
         }
         // Finished batches whose rows have not all been fetched: their waiters do that themselves, in parallel, the
         // moment they see state 4 — the dispatcher only sweeps up what is left after a few rounds' grace (callers that
@@ -1371,7 +1397,7 @@ void co_destroy(kh_engine* e)
 {
     Coalescer* c = e->co;
     if (!c) return;
-    { std::lock_guard<SpinLock> lk(c->mu); c->stop = true; }
+    { std::lock_guard<SpinLock> lk(c->mu); c->stop = true; c->submits.fetch_add(1); }
     c->cv_lane.notify_all();
     if (c->dispatcher.joinable()) c->dispatcher.join();
     (void)hipSetDevice(e->cfg.device);
@@ -1410,19 +1436,20 @@ int co_submit(kh_engine* e, int kind, const kh_board* boards, const float* plane
     const size_t F = e->cfg.features;
     const int cap_rows = kind == 0 ? CO_ROWS : 2 * CO_SMALL_PLANES;
     std::unique_lock<SpinLock> lk(c->mu);
-    CoTicket* t = nullptr;
-    int tid = 0;
-    for (; tid < KH_MAX_OUTSTANDING; ++tid)
-        if (c->tickets[tid].state.load(std::memory_order_acquire) == 0) { t = &c->tickets[tid]; break; }
-    if (!t) return fail(KH_ERR_INVALID, "%d submissions are outstanding on this engine: kh_wait for some before submitting more", KH_MAX_OUTSTANDING);
-    t->state.store(1, std::memory_order_relaxed);      // taken NOW: the wait for a free buffer below drops the lock
+    static_assert(KH_MAX_OUTSTANDING == 64, "free_mask is one 64-bit word");
+    const uint64_t fm = c->free_mask.load(std::memory_order_acquire);
+    if (fm == 0) return fail(KH_ERR_INVALID, "%d submissions are outstanding on this engine: kh_wait for some before submitting more", KH_MAX_OUTSTANDING);
+    const int tid = __builtin_ctzll(fm);               // taken NOW: the wait for a free buffer below drops the lock
+    c->free_mask.fetch_and(~(1ull << tid), std::memory_order_acq_rel);
+    CoTicket* t = &c->tickets[tid];
+    t->state.store(1, std::memory_order_relaxed);
     CoBatch* b = nullptr;
     for (;;) {
         for (auto& x : c->batches)
             if (x.state == 1 && x.kind == kind && !x.full) {
                 if (x.rows + batch <= cap_rows && x.nact + nact <= CO_ACTS) { b = &x; break; }
                 x.full = true;                                   // does not fit: it goes as it is
-                c->cv_lane.notify_all();
+                c->submits.fetch_add(1, std::memory_order_release);
             }
         if (b) break;
         for (auto& x : c->batches)
@@ -1437,6 +1464,7 @@ int co_submit(kh_engine* e, int kind, const kh_board* boards, const float* plane
                     if (set_device(e) || b->pin_in.ensure(o_acts + (size_t)CO_ACTS * 4) || b->pin_out.ensure(o_flags + 128)) {
                         b->state = 0;
                         t->state.store(0, std::memory_order_release);
+                        c->free_mask.fetch_or(1ull << tid, std::memory_order_release);
                         return KH_ERR_HIP;
                     }
                     b->boards = reinterpret_cast<kh_board*>(b->pin_in.at(0));
@@ -1454,15 +1482,19 @@ int co_submit(kh_engine* e, int kind, const kh_board* boards, const float* plane
         }
         c->cv_space.wait(lk);                                    // every buffer is on the device: one of them comes back
     }
-    t->state.store(1, std::memory_order_relaxed); t->status = KH_OK; t->err.clear(); ++t->serial;
-    t->kind = kind; t->row0 = b->rows; t->rows = batch; t->act0 = b->nact; t->nact = nact;
-    t->boards = boards; t->planes = planes; t->offsets = offsets; t->actions = actions;
-    t->priors = priors; t->value = value; t->policy = policy;
+    // under the lock: only what the batch's bookkeeping needs; the ticket's own fields are written after it (the dispatcher
+    // reads them when the launch completes, which is behind `copying` reaching zero)
+    const int row0 = b->rows, act0 = b->nact;
     b->rows += batch; b->nact += nact;
     b->tickets.push_back(t);
     b->copying.fetch_add(1, std::memory_order_relaxed);
-    b->last = std::chrono::steady_clock::now();           // (under the lock: the lanes read it there)
+    b->last = std::chrono::steady_clock::now();           // (under the lock: the dispatcher reads it there)
+    c->submits.fetch_add(1, std::memory_order_release);
     lk.unlock();
+    t->status = KH_OK; t->err.clear(); ++t->serial;
+    t->kind = kind; t->row0 = row0; t->rows = batch; t->act0 = act0; t->nact = nact;
+    t->boards = boards; t->planes = planes; t->offsets = offsets; t->actions = actions;
+    t->priors = priors; t->value = value; t->policy = policy;
     // this caller's rows into the merge buffers (every caller copies its own, in parallel)
     if (kind == 0) {
         memcpy(b->boards + t->row0, boards, (size_t)batch * sizeof(kh_board));
@@ -1472,9 +1504,12 @@ int co_submit(kh_engine* e, int kind, const kh_board* boards, const float* plane
         memcpy(b->planes.data() + (size_t)t->row0 * 64 * F, planes, (size_t)batch * 64 * F * 4);
     }
     const uint32_t serial = t->serial;
-    b->copying.fetch_sub(1, std::memory_order_release);   // (no lock: the lane that has sealed this batch spins on it; after
+    b->copying.fetch_sub(1, std::memory_order_release);   // (no lock: the dispatcher spins on it once it has sealed this batch; after
                                                           //  this the launch may complete and the ticket be waited for)
-    c->cv_lane.notify_all();
+    if (c->asleep.load(std::memory_order_acquire)) {      // (a notify per submission was a std::mutex every caller met at once)
+        std::lock_guard<SpinLock> lk2(c->mu);
+        c->cv_lane.notify_all();
+    }
     *ticket = (int64_t)tid | ((int64_t)serial << 32);
     return KH_OK;
 }
@@ -1522,6 +1557,7 @@ int co_wait(kh_engine* e, int64_t ticket)
     const int rc = t.status;
     if (rc) g_err = t.err;
     t.state.store(0, std::memory_order_release);
+    c->free_mask.fetch_or(1ull << tid, std::memory_order_release);
     return rc;
 }
 
@@ -1929,7 +1965,7 @@ int kh_set_coalesce(kh_engine* e, int target_batch, int max_wait_us)
         return fail(KH_ERR_INVALID, "target_batch in [0, %d], max_wait_us in [0, 1000000]", CO_ROWS);
     e->co_target = target_batch;
     e->co_wait_us = max_wait_us;
-    if (e->co) e->co->cv_lane.notify_all();
+    if (e->co) { e->co->submits.fetch_add(1); e->co->cv_lane.notify_all(); }
     return KH_OK;
 }
 
@@ -1938,7 +1974,7 @@ int kh_set_coalesce_callers(kh_engine* e, int callers)
     if (!e || callers < 0 || callers > KH_MAX_OUTSTANDING) return fail(KH_ERR_INVALID, "callers in [0, %d]", KH_MAX_OUTSTANDING);
     if (callers > 0 && getenv("KAMI_CO_CALLERS") && atoi(getenv("KAMI_CO_CALLERS")) > 0) callers = std::min(callers, atoi(getenv("KAMI_CO_CALLERS")));   // A/B knob: seal at fewer submissions
     e->co_callers = callers;
-    if (e->co) e->co->cv_lane.notify_all();
+    if (e->co) { e->co->submits.fetch_add(1); e->co->cv_lane.notify_all(); }
     return KH_OK;
 }
 

@@ -354,6 +354,7 @@ void worker(ks_pool* p, kh_engine* engine, int g0, int g1, int64_t target_evals,
                 for (unsigned spin = 0; pick < 0; ++spin) {
                     for (int j = 0; j < nsets && pick < 0; ++j) {
                         LeafSet& q = sets[(k + j) % nsets];
+                        __builtin_ia32_pause();
                         int done = 0;
                         const int rc = kh_try_wait(engine, q.ticket, &done);
                         if (!done && rc != KH_OK) throw std::runtime_error(std::string("kh_try_wait: ") + kh_last_error());
