@@ -1192,3 +1192,34 @@ def test_pool_priors_are_the_reference_expansion():
     want = p[0, acts] / p[0, acts].sum()
     np.testing.assert_allclose(pri, want, rtol=1e-5)
     assert abs(pri.sum() - 1.0) < 1e-5
+
+
+def test_split_channel_tower_two_engines_at_once():
+    """tower2s_kernel's workgroups wait for their partners inside the launch (two workgroups per board pair exchange half an
+    image per layer).  Two engines launching it at the same time on their own streams — 2 x 256 workgroups for 256 CUs —
+    must both finish (partners are neighbours in each XCD's dispatch order, so whatever is resident can always complete)
+    and give the bits of a launch that had the chip to itself; a partner that never showed up would raise the NaN flag
+    after a second instead of hanging the device."""
+    import threading
+    F, C, R, B = 119, 256, 3, 256
+    blob = W.random_weights(F, C, R, seed=9, peaky=10.0)
+    x = np.random.default_rng(3).random((B, 8, 8, F), dtype=np.float32)
+    nns = [NN(8, 8, F, 4672, filters=C, residuals=R, dtype="f16") for _ in range(2)]
+    for nn in nns:
+        nn.load_weights(blob, 1)
+    want = nns[0].infer_full(x)
+    errors = []
+
+    def work(nn):
+        try:
+            for _ in range(40):
+                got = nn.infer_full(x)
+                if not all(np.array_equal(a, b) for a, b in zip(got, want)):
+                    errors.append("bits")
+        except Exception as e:                      # noqa: BLE001
+            errors.append(repr(e))
+
+    th = [threading.Thread(target=work, args=(nn,)) for nn in nns]
+    [t.start() for t in th]
+    [t.join() for t in th]
+    assert not errors, errors[:3]
