@@ -683,8 +683,10 @@ int forward_layers(kh_engine* e, const Weights& W, Slot& s, const float* d_in, i
     if (rc) return KH_ERR_HIP;
     hipStream_t st = s.stream;
     int* flags = s.flags.as<int>();
-    HIPCHK(hipMemsetAsync(flags, 0, 16, st));
-    s.flags_clean = false;
+    if (!s.flags_clean) {               // as in forward_tower: the kernels only ever OR into the flags, whoever reads a raised
+        HIPCHK(hipMemsetAsync(flags, 0, 16, st));       // one marks the slot dirty — no memset node per forward
+        s.flags_clean = true;
+    }
     kh::LayersArgs L;
     L.in = d_in; L.B = B; L.F = e->cfg.features; L.FP = W.ly_FP; L.CP = W.ly_CP; L.R = e->cfg.residuals;
     L.act_in = s.actin.as<unsigned short>();

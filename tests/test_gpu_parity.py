@@ -201,6 +201,9 @@ def test_forward_wide_nets_vs_oracle(dtype, F, C, R, B):
     with pytest.raises(KamiError) as ei:
         nn.infer(xb)
     assert ei.value.status == L.KH_ERR_NAN_POLICY
+    # ... and the raised flag does not outlive the call that reported it (the flags are cleared on demand, not per forward)
+    p2, _ = nn.infer(x)
+    assert np.array_equal(p2, p)
 
 
 @pytest.mark.parametrize("dtype", ["bf16", "f16"])
