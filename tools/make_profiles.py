@@ -14,10 +14,14 @@ tag = f"r{rnd:02d}"
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
+# device code of the whole-network forward kernel and its launcher (host-side engine code, other kernels: not part of it)
+HEADLINE_KERNEL_FILES = ("kh_internal.h", "tower_common.h", "tower_mfma.hip", "tower8_mfma.hip")
+
+
 def kernel_source_sha():
     h = hashlib.sha256()
-    for f in sorted(glob.glob(os.path.join(ROOT, "kami_amd", "csrc", "*.hip")) + glob.glob(os.path.join(ROOT, "kami_amd", "csrc", "*.h"))):
-        h.update(open(f, "rb").read())
+    for name in HEADLINE_KERNEL_FILES:
+        h.update(open(os.path.join(ROOT, "kami_amd", "csrc", name), "rb").read())
     return h.hexdigest()[:16]
 
 
