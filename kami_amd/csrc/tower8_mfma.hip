@@ -419,8 +419,15 @@ __device__ __forceinline__ void zero_halo(char* base, int board_bytes, int t)
 // The value head's second half on the four helper waves: valuefc + tanh -> [B][256] (nn.cpp:86-88), thread j = output j.
 // The row is requested behind [BL], waits in registers while the compute waves reduce their logits ([BS1], [BS2]) and
 // is used while they scale and store the policy rows: off the workgroup's tail.  v64: the value conv's [TW_NB][64] in LDS.
+#if KAMI_TOWER_STAMP
+#define FC_STAMP(k) do { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); if (lane == 0) fc_stamps[k] = t_; } while (0)
+#define FC_STAMP_ARG , stamps + wave * 32
+#else
+#define FC_STAMP(k) do { } while (0)
+#define FC_STAMP_ARG
+#endif
 template <bool LEGAL>
-__device__ __forceinline__ void helper_value_fc(const TowerArgs& a, const float* v64, int b0, int j, int lane)
+__device__ __forceinline__ void helper_value_fc(const TowerArgs& a, const float* v64, int b0, int j, int lane, unsigned long long* fc_stamps = nullptr)
 {
     asm volatile("s_barrier" ::: "memory");                                                 // [BL]
     unsigned voff = (unsigned)j * 16u;        // (opaque: the optimiser would hoist 16 address pairs out of the group loop and spill them)
@@ -431,8 +438,11 @@ __device__ __forceinline__ void helper_value_fc(const TowerArgs& a, const float*
         fcw[k] = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(a.fcw4) + (size_t)k * KH_VALUE_WIDTH * 16 + voff);
     const float fcbias = a.fcb[j];
     __builtin_amdgcn_sched_barrier(0);
+    FC_STAMP(10);
     asm volatile("s_barrier" ::: "memory");                                                 // [BS1]
+    FC_STAMP(11);
     asm volatile("s_barrier" ::: "memory");                                                 // [BS2]
+    FC_STAMP(12);
     // (the sums between [BS1] and [BS2] instead of behind [BS2]: no difference, 30.58 / 30.62 us on one device)
     float s[TW_NB];
 #pragma unroll
@@ -452,13 +462,19 @@ __device__ __forceinline__ void helper_value_fc(const TowerArgs& a, const float*
             s[bb] = fmaf(x.z, w.z, s[bb]); s[bb] = fmaf(x.w, w.w, s[bb]);
         }
     }
+    FC_STAMP(13);
     bool nan = false;
 #pragma unroll
     for (int bb = 0; bb < TW_NB; ++bb) {
         if (b0 + bb < a.B) {
-            const float r = tanhf(s[bb] + fcbias);
+            const float r = tanhf(s[bb] + fcbias);        // (1 - 2 / (1 + e^2x) on v_exp / v_rcp instead: no change, 32.05 vs 32.10 us — the
+                                                          //  2 000 clocks between the sums and the end are the stores queueing behind the policy rows')
             nan |= (r != r);
+#if defined(T8_VFULL_PLAIN)
+            a.vfull[(size_t)(b0 + bb) * KH_VALUE_WIDTH + j] = r;
+#else
             store_wt(a.vfull + (size_t)(b0 + bb) * KH_VALUE_WIDTH + j, r);
+#endif
             if (LEGAL && j == 0) a.lg_values[b0 + bb] = r;               // column 0: the position's value
         }
     }
@@ -666,7 +682,7 @@ __global__ __launch_bounds__(512) void tower8_kernel(TowerArgs a)
                 }
             }
             T8_STAMP(19);
-            helper_value_fc<LEGAL>(a, v64, b0, tid & 255, lane);                            // [BL] [BS1] [BS2] inside
+            helper_value_fc<LEGAL>(a, v64, b0, tid & 255, lane FC_STAMP_ARG);                            // [BL] [BS1] [BS2] inside
             T8_STAMP(21);
             asm volatile("s_barrier" ::: "memory");                                         // [BE]
             T8_STAMP(22);
@@ -689,7 +705,7 @@ __global__ __launch_bounds__(512) void tower8_kernel(TowerArgs a)
             T8_STAMP(19);
             // (the stream is at rest until the next group's first step: these loads and stores are the youngest
             //  operations, every ring piece older than them has long landed)
-            helper_value_fc<LEGAL>(a, v64, grp * TW_NB, tid & 255, lane);                   // [BL] [BS1] [BS2] inside
+            helper_value_fc<LEGAL>(a, v64, grp * TW_NB, tid & 255, lane FC_STAMP_ARG);                   // [BL] [BS1] [BS2] inside
             T8_STAMP(21);
             asm volatile("s_barrier" ::: "memory");                                         // [BE]
             T8_STAMP(22);

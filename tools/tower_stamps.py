@@ -36,7 +36,7 @@ if a.v8:
     t0 = st[:, :, 0].min(axis=1)[:, None]
     print("cycles since the workgroup's first compute-wave stamp (median over workgroups and the role's two waves):")
     for role, w0, items in (("plane waves", 2, ((0, "entry"), (10, "quarter 0 loads issued"), (11, "quarter 1 loads issued"), (12, "quarter 2 loads issued"), (13, "quarter 3 loads issued"), (6, "plane loads issued"), (14, "quarter 0 landed (STAMP=2 builds)"), (15, "quarter 1 landed"), (16, "quarter 2 landed"), (17, "quarter 3 landed"), (8, "quarter 0 converted"), (2, "[B0] passed"), (5, "stem steps done"), (19, "all steps done"), (22, "group done"))),
-                            ("stream waves", 0, ((0, "entry"), (2, "[B0] passed"), (19, "all steps done"), (21, "value fc done"), (22, "group done"), (23, "drained")))):
+                            ("stream waves", 0, ((0, "entry"), (2, "[B0] passed"), (19, "all steps done"), (10, "fc: row requested behind [BL]"), (11, "fc: [BS1] passed"), (12, "fc: [BS2] passed"), (13, "fc: sums done"), (21, "value fc done (tanh, stores issued)"), (22, "group done"), (23, "drained")))):
         print(f" {role}:")
         for k, nm in items:
             print(f"   {nm:34s} {np.median(hs[:, w0:w0 + 2, k] - t0):8.0f}")
