@@ -1671,6 +1671,7 @@ int kh_train(kh_engine* e, const float* inputs, const float* obs_p, const float*
 {
     if (!e || !inputs || !obs_p || !obs_v || !cfg) return fail(KH_ERR_INVALID, "null argument");
     if (trajectories < 1 || cfg->batch < 2 || cfg->epochs < 1) return fail(KH_ERR_INVALID, "trajectories >= 1, batch >= 2, epochs >= 1 required");
+    const auto t_call = std::chrono::steady_clock::now();
     auto W = current_weights(e);
     if (!W) return fail(KH_ERR_NO_WEIGHTS, "kh_train before kh_load_weights");
     int rc = set_device(e);
@@ -1719,6 +1720,7 @@ int kh_train(kh_engine* e, const float* inputs, const float* obs_p, const float*
     bool& graph_tried = tc.graph_tried;
     HIPCHK(kh::conv_f32_raw_prepare());          // function attributes are not stream work: set them before any capture
     static const bool trace = getenv("KAMI_TRAIN_TRACE") != nullptr;
+    const auto t_setup = std::chrono::steady_clock::now();
     for (int epoch = 0; epoch < cfg->epochs; ++epoch) {
         std::shuffle(picker.begin(), picker.end(), rng);
         float avgloss = 0.0f;
@@ -1773,11 +1775,19 @@ int kh_train(kh_engine* e, const float* inputs, const float* obs_p, const float*
         if (!epoch) firstloss = avgloss;
         lastloss = avgloss;
     }
+    const auto t_steps = std::chrono::steady_clock::now();
     std::vector<float> blob(nfl);
     HIPCHK(hipMemcpy(blob.data(), params.p, nfl * 4, hipMemcpyDeviceToHost));
     if (first_loss) *first_loss = firstloss;
     if (last_loss) *last_loss = lastloss;
-    return kh_load_weights(e, blob.data(), nfl, W->generation + 1);         // nn.cpp:371 ++generation
+    const auto t_read = std::chrono::steady_clock::now();
+    const int lrc = kh_load_weights(e, blob.data(), nfl, W->generation + 1);         // nn.cpp:371 ++generation
+    if (trace) {
+        auto ms = [](std::chrono::steady_clock::duration d) { return std::chrono::duration<double, std::milli>(d).count(); };
+        fprintf(stderr, "[kami train] call: set-up %.2f ms, steps %.2f ms, parameters back %.2f ms, weights installed %.2f ms\n",
+                ms(t_setup - t_call), ms(t_steps - t_setup), ms(t_read - t_steps), ms(std::chrono::steady_clock::now() - t_read));
+    }
+    return lrc;
 }
 
 int kh_train_order(int trajectories, int epochs, int32_t* order)
