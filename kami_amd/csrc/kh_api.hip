@@ -496,7 +496,10 @@ struct Coalescer;       // the submit / wait queue, below
 
 struct TrainCache {
     DevMem params, grads, work, dx, dp, dv, dloss;
-    PinMem pin;
+    PinMem pin, pin_params;                     // batch staging; the parameter blob on its way up (a pageable source made the
+                                                // upload take 0.1 ms or 10-27 ms from call to call: the runtime pins it on the fly)
+    std::weak_ptr<Weights> on_device;           // the weights whose blob `params` holds right now (the previous call's result):
+                                                // training them again needs no upload at all
     hipStream_t st = nullptr;
     hipGraph_t g = nullptr;
     hipGraphExec_t x = nullptr;
@@ -1640,7 +1643,7 @@ void kh_destroy(kh_engine* e)
     delete e;
 }
 
-int kh_load_weights(kh_engine* e, const float* blob, size_t nfloats, int generation)
+static int load_weights_impl(kh_engine* e, const float* blob, size_t nfloats, int generation, std::shared_ptr<Weights>* installed)
 {
     if (!e || !blob) return fail(KH_ERR_INVALID, "null argument");
     const int F = e->cfg.features, C = e->cfg.filters, R = e->cfg.residuals;
@@ -1663,7 +1666,13 @@ int kh_load_weights(kh_engine* e, const float* blob, size_t nfloats, int generat
     std::lock_guard<std::mutex> lk(e->wmu);
     e->weights = W;                  // calls in flight keep their own reference
     e->has_weights.store(true, std::memory_order_release);
+    if (installed) *installed = W;
     return KH_OK;
+}
+
+int kh_load_weights(kh_engine* e, const float* blob, size_t nfloats, int generation)
+{
+    return load_weights_impl(e, blob, nfloats, generation, nullptr);
 }
 
 int kh_train(kh_engine* e, const float* inputs, const float* obs_p, const float* obs_v, int trajectories,
@@ -1692,11 +1701,20 @@ int kh_train(kh_engine* e, const float* inputs, const float* obs_p, const float*
             return rc;
         // the recorded step holds buffer addresses, the batch size, the learning rate and the kernel choice
         if (before[0] != params.p || before[1] != work.p || before[2] != dx.p || tc.B != B || tc.lr != cfg->lr || tc.valu != valu_now) tc.drop_graph();
+        if (before[0] != params.p) tc.on_device.reset();
         tc.B = B; tc.lr = cfg->lr; tc.valu = valu_now;
     }
+    const auto t_bufs = std::chrono::steady_clock::now();
     if (!tc.st) HIPCHK(hipStreamCreateWithFlags(&tc.st, hipStreamNonBlocking));
     hipStream_t st = tc.st;
-    HIPCHK(hipMemcpyAsync(params.p, W->blob.data(), nfl * 4, hipMemcpyHostToDevice, st));
+    if (tc.on_device.lock() != W) {
+        // through a page-locked block of the trainer's own (the blob is a std::vector)
+        if (tc.pin_params.ensure(nfl * 4)) return KH_ERR_HIP;
+        memcpy(tc.pin_params.p, W->blob.data(), nfl * 4);
+        HIPCHK(hipMemcpyAsync(params.p, tc.pin_params.p, nfl * 4, hipMemcpyHostToDevice, st));
+    }                                            // else: `params` still holds exactly these weights — the previous call trained them
+    tc.on_device.reset();                        // (until this call has installed its result, `params` belongs to nobody)
+    const auto t_up = std::chrono::steady_clock::now();
 
     // nn.cpp:245-262: one engine for the whole call, one shuffle per epoch; staging rows persist
     std::vector<int> picker((size_t)trajectories);
@@ -1781,11 +1799,14 @@ int kh_train(kh_engine* e, const float* inputs, const float* obs_p, const float*
     if (first_loss) *first_loss = firstloss;
     if (last_loss) *last_loss = lastloss;
     const auto t_read = std::chrono::steady_clock::now();
-    const int lrc = kh_load_weights(e, blob.data(), nfl, W->generation + 1);         // nn.cpp:371 ++generation
+    std::shared_ptr<Weights> installed;
+    const int lrc = load_weights_impl(e, blob.data(), nfl, W->generation + 1, &installed);         // nn.cpp:371 ++generation
+    if (lrc == KH_OK) tc.on_device = installed;
     if (trace) {
         auto ms = [](std::chrono::steady_clock::duration d) { return std::chrono::duration<double, std::milli>(d).count(); };
-        fprintf(stderr, "[kami train] call: set-up %.2f ms, steps %.2f ms, parameters back %.2f ms, weights installed %.2f ms\n",
-                ms(t_setup - t_call), ms(t_steps - t_setup), ms(t_read - t_steps), ms(std::chrono::steady_clock::now() - t_read));
+        fprintf(stderr, "[kami train] call: set-up %.2f ms (buffers %.2f, parameters up %.2f, staging %.2f), steps %.2f ms, parameters back %.2f ms, "
+                "weights installed %.2f ms\n", ms(t_setup - t_call), ms(t_bufs - t_call), ms(t_up - t_bufs), ms(t_setup - t_up),
+                ms(t_steps - t_setup), ms(t_read - t_steps), ms(std::chrono::steady_clock::now() - t_read));
     }
     return lrc;
 }
