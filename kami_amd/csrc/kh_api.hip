@@ -128,7 +128,7 @@ struct Weights {
     bool tw_ok = false;
     std::string tw_why;
     // per-layer MFMA path for wide nets (layers_mfma.hip)
-    DevMem ly_w, ly_shift, ly_misc;      // ly_misc: vw[CP], fcw[256*64], fcb[256]
+    DevMem ly_w, ly_shift, ly_misc;      // ly_misc: vw[CP], fcw[256*64], fcb[256], fc4[16][256][4]
     DevMem ly_w4;                        // 3x3 layers once more, packed for conv4_mfma_kernel
     DevMem ly_w2b;                       // stem + tower packed for tower256_kernel (256-channel blocks)
     bool ly_w2b_ok = false;
@@ -333,12 +333,20 @@ int build_layers(Weights& W, const HostNet& n, int dtype, int F, int C, int R)
         run();
         for (auto& t : th) t.join();
     }
-    std::vector<float> misc((size_t)CP + KH_VALUE_WIDTH * 64 + KH_VALUE_WIDTH, 0.0f);
+    std::vector<float> misc((size_t)CP + KH_VALUE_WIDTH * 64 + KH_VALUE_WIDTH + (size_t)KH_VALUE_WIDTH * 64, 0.0f);      // ... + fc4
     float vs, vsh;
     fold_bn(n.vconv, 1, &vs, &vsh);
     for (int i = 0; i < C; ++i) misc[i] = n.vconv.w[i] * vs;
     memcpy(misc.data() + CP, n.fcw, sizeof(float) * KH_VALUE_WIDTH * 64);
     memcpy(misc.data() + CP + (size_t)KH_VALUE_WIDTH * 64, n.fcb, sizeof(float) * KH_VALUE_WIDTH);
+    {
+        // valuefc.weight once more as [k / 4][output][4]: 64 lanes that take 64 consecutive outputs read 1 KB in one piece per
+        // k-group (policy_head4_kernel / tower128_kernel's value FC; from the [256][64] rows every lane's 16 bytes were a
+        // cache line of their own: 24 000 clocks of a 48 000-clock head)
+        float* fc4 = misc.data() + CP + (size_t)KH_VALUE_WIDTH * 64 + KH_VALUE_WIDTH;
+        for (int j = 0; j < KH_VALUE_WIDTH; ++j)
+            for (int k = 0; k < 64; ++k) fc4[((size_t)(k / 4) * KH_VALUE_WIDTH + j) * 4 + (k & 3)] = n.fcw[(size_t)j * 64 + k];
+    }
     W.ly_vshift = vsh; W.ly_FP = FP; W.ly_CP = CP;
     const void* wsrc = f32 ? (const void*)wf.data() : (const void*)w.data();
     const size_t wbytes = f32 ? wf.size() * 4 : w.size() * 2;
@@ -705,6 +713,7 @@ int forward_layers(kh_engine* e, const Weights& W, Slot& s, const float* d_in, i
     L.w2b = W.ly_w2b_ok ? W.ly_w2b.as<unsigned short>() : nullptr;
     L.policy = d_policy; L.flags = flags; L.want_logits = d_logits_out != nullptr;
     L.fcw = W.ly_misc.as<float>() + W.ly_CP; L.fcb = L.fcw + (size_t)KH_VALUE_WIDTH * 64; L.vfull = d_vfull;
+    L.fc4 = L.fcb + KH_VALUE_WIDTH;
     L.num_cus = e->num_cus;
     if (W.ly_CP == 256 && W.ly_w2b_ok && e->cfg.dtype != KH_F32 && 16 * (((B + 1) / 2 + 7) / 8) <= e->num_cus) {
         // tower2s_kernel's exchange area (two workgroups per board pair at batches that leave half the chip idle)

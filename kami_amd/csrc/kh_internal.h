@@ -107,6 +107,7 @@ struct LayersArgs {
     bool want_logits;              // the caller asked for the pre-softmax logits in `logits`
     const float* fcw;              // valuefc.weight [256][64], .bias [256] (device); launch_layers runs the value FC too
     const float* fcb;
+    const float* fc4 = nullptr;    // valuefc.weight as [k / 4][256][4] (nullable: the kernels then read `fcw`)
     float* vfull;                  // [B][256]
     // tower2s_kernel's exchange area (nullable): [x_pairs][2] flags 64 bytes apart, then [2][x_pairs][2][128][128] T
     unsigned* xflag = nullptr;

@@ -39,6 +39,18 @@ using f32x4s = __attribute__((ext_vector_type(4))) float;
 #ifndef KAMI_WIDE_BUFA
 #define KAMI_WIDE_BUFA 1           // tower2b / tower2s weight fragments by buffer loads (0: global loads, the A/B baseline)
 #endif
+// the policy heads' softmax (policy_head4_kernel and tower128_kernel<T, true>: one arithmetic, every batch size): v_exp_f32 /
+// v_log_f32 forms (2 ulp) instead of ocml's expf / logf — 256 calls per lane were 8-10 us of a 28 us head
+#ifndef KAMI_HEAD_FAST_EXP
+#define KAMI_HEAD_FAST_EXP 1
+#endif
+#if KAMI_HEAD_FAST_EXP
+#define HEAD_EXP(x) __expf(x)
+#define HEAD_LOG(x) __logf(x)
+#else
+#define HEAD_EXP(x) expf(x)
+#define HEAD_LOG(x) logf(x)
+#endif
 #ifndef KAMI_T2B_NA
 #define KAMI_T2B_NA 12           // tower2b_kernel: k-steps of weight fragments in flight (4 -> 12: 10x128 at batch 512 198 -> 186 us, 20x256 +0.5 %)
 #endif
@@ -132,6 +144,19 @@ struct ConvArgs {
 constexpr int RD = 4;
 constexpr int CHUNKB = 8192;
 constexpr int LDS_IMG = RD * CHUNKB;
+
+// the same for a chunk given by its address, into slot `slot` (a second stream joining the first: tower128_kernel's heads)
+__device__ __forceinline__ void ring_issue_at(const char* chunk, int slot, int wave, int lane)
+{
+    const char* sbase = chunk + wave * 2048;
+    const unsigned dst = (unsigned)(slot * CHUNKB + wave * 2048);
+    const unsigned voff = lane * 16;
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\t"
+                 "global_load_lds_dwordx4 %1, %2\n\tglobal_load_lds_dwordx4 %1, %2 offset:1024\n\t"
+                 "s_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(voff), "s"(sbase), "s"(dst) : "memory");
+}
 
 template <int RDN = RD>
 __device__ __forceinline__ void ring_issue(const char* stream, int nch, int c, int wave, int lane)
@@ -572,6 +597,37 @@ __device__ unsigned long long g_t128_stamps[256 * 64 * 4];
 #define T128_STAMP(l, k) do {} while (0)
 #endif
 
+struct Head4Args {
+    const unsigned short* x;      // T [B][64][Ci], Ci = NP * 128
+    const unsigned short* w;      // policyconv chunks (Ci / 32 of 8 KB) then policyconv2 chunks (4), pack_layer_wide128 order
+    const float* shift1;          // [128] folded pbatchnorm shift
+    const float* bias2;           // [128] policyconv2 bias, planes >= 73 zero
+    float* policy;                // [B][4672]
+    float* logits;                // nullable [B][4672]
+    int* flags;                   // [0]: a NaN in some policy row (nn.cpp:176-177); [1]: in the value tensor (nn.cpp:179-180)
+    int B;
+    // value head (nn.cpp:83-88), nullable as a whole (vw == nullptr: the separate kernels run it)
+    const float* vw;              // [Ci] valueconv weight * vbatchnorm scale
+    float vshift;
+    const float* fcw;             // [256][64] valuefc.weight
+    const float* fcb;             // [256]
+    const float* fc4;             // valuefc.weight as [k / 4][256][4]
+    float* vfull;                 // [B][256]
+};
+
+__device__ __forceinline__ float wave_max_f(float v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+__device__ __forceinline__ float wave_sum_f(float v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
 struct Tower128Args {
     const float* planes;          // fp32 [B][64][F] (nn.cpp:157), converted while they are staged; nullptr: take `in`
     int F;                        // planes per pixel, <= 128
@@ -579,11 +635,15 @@ struct Tower128Args {
     const unsigned short* in;     // T [B][64][128]: the planes, converted and zero-padded (planes_to_act_kernel)
     const unsigned short* w;      // (1 + 2R) layers x 36 chunks of 8 KB, pack_layer_wide128 order (Co = Ci = 128)
     const float* shift;           // (1 + 2R) x 128 folded BatchNorm shifts
-    unsigned short* out;          // T [B][64][128]: the residual stream after the last block
+    unsigned short* out;          // T [B][64][128]: the residual stream after the last block (HEAD: not written)
     int B, R;
+    Head4Args hd;                 // HEAD: both heads on the board each wave owns, the weight ring running on into hd.w (8 chunks)
 };
 
-template <typename T>
+// HEAD (round 3): policy_head4_kernel<T, 1>'s work appended — same arithmetic in the same order, so the same bits — on the
+// image the last boundary has just written: no second launch, no 16.8 MB of residual stream out and in again per 1 024
+// boards, no staging; the ring's prefetch past the tower's last chunk fetches the heads' weights instead of a dummy.
+template <typename T, bool HEAD>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void tower128_kernel(Tower128Args a)
 {
     constexpr int RDN = 4;
@@ -599,6 +659,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     constexpr int NCH = 36;
     const int NL = 1 + 2 * a.R, NCHT = NL * NCH;
     const char* stream = reinterpret_cast<const char*>(a.w);
+    const char* hstream = reinterpret_cast<const char*>(a.hd.w);
     char* img = smem + LDS_IMG;
 
 #pragma unroll
@@ -751,7 +812,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             const int g = l * NCH + n;
             asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(2 * (RDN - 3)) : "memory");
             __builtin_amdgcn_sched_barrier(0);
-            ring_issue<RDN>(stream, NCHT, g + RDN - 1, wave, lane);
+            if (!HEAD || g + RDN - 1 < NCHT) ring_issue<RDN>(stream, NCHT, g + RDN - 1, wave, lane);
+            else ring_issue_at(hstream + (size_t)(g + RDN - 1 - NCHT < 8 ? g + RDN - 1 - NCHT : 7) * CHUNKB, (g + RDN - 1) % RDN, wave, lane);   // the heads' chunks follow the tower's
             if (n == NCH - 2) request_shift(l + 1);
             const unsigned a_off = (unsigned)(((n + 1) % RDN) * CHUNKB) + lane * 16;      // 36 chunks per layer: slot = n % 4
 #pragma unroll
@@ -783,6 +845,185 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         T128_STAMP(l, 3);
         shift_to_acc();
         T128_STAMP(l, 2);
+    }
+    if constexpr (HEAD) {
+        // ---- both heads (nn.cpp:72-88) on this wave's board, policy_head4_kernel<T, 1>'s arithmetic in its order.  The image
+        // holds the residual stream after the last block (the boundary has just written it); chunk NCHT + n of the ring is
+        // the heads' chunk n; the tower's register sets (A / Bq parities, accumulators) carry straight on.
+        const Head4Args& hd = a.hd;
+        const unsigned hb_base = b_base + (PITCH + 1) * stride;         // the centre tap: the board's own pixels
+        float vsum[2] = { 0.0f, 0.0f };                      // valueconv partial sums of this lane's two pixels, its half of the channels
+        if (hd.vw) {
+            const float* vw = hd.vw + 64 * h;
+#pragma unroll
+            for (int c8 = 0; c8 < 8; ++c8) {                 // (the weights once for both pixels; each pixel's sum in channel order as before)
+                const float4 w0 = *reinterpret_cast<const float4*>(vw + c8 * 8), w1 = *reinterpret_cast<const float4*>(vw + c8 * 8 + 4);
+#pragma unroll
+                for (int hp = 0; hp < 2; ++hp) {
+                    const char* row = smem + LDS_IMG + wave * board_bytes + ((4 * hp + py + 1) * PITCH + px + 1) * stride + h * 128;
+                    const u32x4 u = *reinterpret_cast<const u32x4*>(row + c8 * 16);
+                    float sacc = vsum[hp];
+                    sacc = fmaf(from_bits<T>((unsigned short)(u.x & 0xffff)), w0.x, sacc); sacc = fmaf(from_bits<T>((unsigned short)(u.x >> 16)), w0.y, sacc);
+                    sacc = fmaf(from_bits<T>((unsigned short)(u.y & 0xffff)), w0.z, sacc); sacc = fmaf(from_bits<T>((unsigned short)(u.y >> 16)), w0.w, sacc);
+                    sacc = fmaf(from_bits<T>((unsigned short)(u.z & 0xffff)), w1.x, sacc); sacc = fmaf(from_bits<T>((unsigned short)(u.z >> 16)), w1.y, sacc);
+                    sacc = fmaf(from_bits<T>((unsigned short)(u.w & 0xffff)), w1.z, sacc); sacc = fmaf(from_bits<T>((unsigned short)(u.w >> 16)), w1.w, sacc);
+                    vsum[hp] = sacc;
+                }
+            }
+        }
+        auto init_acc = [&](const float* shp) {
+#pragma unroll
+            for (int ms = 0; ms < 4; ++ms)
+#pragma unroll
+                for (int g4 = 0; g4 < 4; ++g4) {
+                    const float4 s4 = *reinterpret_cast<const float4*>(shp + ms * 32 + 8 * g4 + 4 * h);
+#pragma unroll
+                    for (int hp = 0; hp < 2; ++hp) {
+                        acc[ms * 2 + hp][4 * g4 + 0] = s4.x; acc[ms * 2 + hp][4 * g4 + 1] = s4.y;
+                        acc[ms * 2 + hp][4 * g4 + 2] = s4.z; acc[ms * 2 + hp][4 * g4 + 3] = s4.w;
+                    }
+                }
+        };
+        auto hchunk_off = [](int n) -> unsigned { return (unsigned)((n >> 1) * 128 + (n & 1) * 64); };
+        // four chunk steps of a 1x1 convolution over the board's own pixels; G0: the first chunk's number in the ring
+        auto four_steps = [&](int G0) {
+#pragma unroll
+            for (int k2 = 0; k2 < 2; ++k2)
+#pragma unroll
+                for (int hp = 0; hp < 2; ++hp) Bq[0][k2 * 2 + hp] = *reinterpret_cast<const V*>(smem + hb_base + hp * HALF + hchunk_off(0) + k2 * 32);
+#pragma unroll
+            for (int n = 0; n < 4; ++n) {
+                const int cur = n & 1, nxt = cur ^ 1, g = G0 + n;
+                asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(2 * (RDN - 3)) : "memory");
+                __builtin_amdgcn_sched_barrier(0);
+                ring_issue_at(hstream + (size_t)(g + RDN - 1 - NCHT < 8 ? g + RDN - 1 - NCHT : 7) * CHUNKB, (g + RDN - 1) % RDN, wave, lane);
+                const unsigned a_off = (unsigned)(((n + 1) % RDN) * CHUNKB) + lane * 16;       // NCHT % 4 == 0: slot = n
+#pragma unroll
+                for (int f = 0; f < 8; ++f) A[nxt][f] = *reinterpret_cast<const V*>(smem + a_off + f * 1024);
+                if (n + 1 < 4) {
+#pragma unroll
+                    for (int k2 = 0; k2 < 2; ++k2)
+#pragma unroll
+                        for (int hp = 0; hp < 2; ++hp) Bq[nxt][k2 * 2 + hp] = *reinterpret_cast<const V*>(smem + hb_base + hp * HALF + hchunk_off(n + 1) + k2 * 32);
+                }
+#pragma unroll
+                for (int k2 = 0; k2 < 2; ++k2)
+#pragma unroll
+                    for (int ms = 0; ms < 4; ++ms)
+#pragma unroll
+                        for (int hp = 0; hp < 2; ++hp) acc[ms * 2 + hp] = Elem<T>::mfma(A[cur][k2 * 4 + ms], Bq[cur][k2 * 2 + hp], acc[ms * 2 + hp]);
+#pragma unroll
+                for (int i = 0; i < 12; ++i) {
+                    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                }
+                __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+            }
+        };
+        T128_STAMP(NL, 0);
+        init_acc(hd.shift1);
+        four_steps(NCHT);
+        T128_STAMP(NL, 1);
+        // policyconv's output (pbatchnorm folded, ReLU, rounded to T) -> this wave's image, in place
+#pragma unroll
+        for (int hp = 0; hp < 2; ++hp)
+#pragma unroll
+            for (int ms = 0; ms < 4; ++ms)
+#pragma unroll
+                for (int g4 = 0; g4 < 4; ++g4) {
+                    float v[4];
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) v[i] = relu_keep_nan(acc[ms * 2 + hp][4 * g4 + i]);
+                    *reinterpret_cast<u32x2*>(w_base + hp * HALF + (ms * 32 + 8 * g4) * 2) = u32x2{ pack2<T>(v[0], v[1]), pack2<T>(v[2], v[3]) };
+                }
+        init_acc(hd.bias2);
+        four_steps(NCHT + 4);
+        T128_STAMP(NL, 2);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // drain the ring (tail re-fetches) before its memory is reused
+        // ---- softmax over the board's 64 pixels x 73 planes, all inside this wave
+        const int b = b0 + wave;
+        float m = -INFINITY;
+        bool nan = false;
+#pragma unroll
+        for (int i8 = 0; i8 < 8; ++i8)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int ch = (i8 >> 1) * 32 + 8 * (r >> 2) + 4 * h + (r & 3);
+                if (ch < KH_POLICY_PLANES) { const float v = acc[i8][r]; nan |= (v != v); m = fmaxf(m, v); }
+            }
+        m = wave_max_f(m);
+        float sum = 0.0f;
+#pragma unroll
+        for (int i8 = 0; i8 < 8; ++i8)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int ch = (i8 >> 1) * 32 + 8 * (r >> 2) + 4 * h + (r & 3);
+                if (ch < KH_POLICY_PLANES) sum += HEAD_EXP(acc[i8][r] - m);
+            }
+        sum = wave_sum_f(sum);
+        const float ls = HEAD_LOG(sum);
+        const bool row_nan = __any(nan);
+        T128_STAMP(NL, 3);
+        __syncthreads();                                   // ring and images are dead: the rows go through their memory
+        float* rowbuf = reinterpret_cast<float*>(smem) + wave * KH_PSIZE;
+        const bool live = b < a.B;
+        const int lpix = py * 8 + px;                      // this lane's pixel within a 32-pixel half
+        auto put_row = [&](float* dst_row, bool probs) {
+#pragma unroll
+            for (int hp = 0; hp < 2; ++hp)
+#pragma unroll
+                for (int ms = 0; ms < 3; ++ms)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int ch = ms * 32 + 8 * (r >> 2) + 4 * h + (r & 3);
+                        if (ch < KH_POLICY_PLANES) {
+                            const float v = acc[ms * 2 + hp][r];
+                            rowbuf[(32 * hp + lpix) * KH_POLICY_PLANES + ch] = probs ? (row_nan ? NAN : HEAD_EXP((v - m) - ls)) : v;
+                        }
+                    }
+            if (live) {
+                for (int i = lane; i < KH_PSIZE / 4; i += 64)
+                    asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(reinterpret_cast<f32x4s*>(dst_row) + i), "v"(*reinterpret_cast<const f32x4s*>(rowbuf + 4 * i)) : "memory");
+            }
+        };
+        if (hd.logits) put_row(hd.logits + (size_t)(live ? b : 0) * KH_PSIZE, false);
+        put_row(hd.policy + (size_t)(live ? b : 0) * KH_PSIZE, true);
+        T128_STAMP(NL + 1, 0);
+        if (!live) return;
+        if (row_nan && lane == 0) atomicOr(&hd.flags[0], 1);
+        if (hd.vw) {
+            float* v64 = reinterpret_cast<float*>(smem + 80 * 1024) + wave * 64;     // behind the four rows (74.75 KB), in the dead images
+#pragma unroll
+            for (int hp = 0; hp < 2; ++hp) {
+                const unsigned u = __float_as_uint(vsum[hp]);
+                const auto sw = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+                const float tot = __uint_as_float(sw[0]) + __uint_as_float(sw[1]);
+                if (h == 0) v64[32 * hp + lpix] = relu_keep_nan(tot + hd.vshift);
+            }
+            // lane l: outputs l, l + 64, l + 128, l + 192 (consecutive lanes, consecutive 16 bytes of fc4); the sums run over k in
+            // the order they always did, so the same bits
+            float o[4] = { hd.fcb[lane], hd.fcb[lane + 64], hd.fcb[lane + 128], hd.fcb[lane + 192] };
+#pragma unroll 4
+            for (int k4 = 0; k4 < 16; ++k4) {
+                const float4 hv = *reinterpret_cast<const float4*>(v64 + k4 * 4);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const float4 wv = *reinterpret_cast<const float4*>(hd.fc4 + ((size_t)k4 * KH_VALUE_WIDTH + lane + 64 * j) * 4);
+                    o[j] = fmaf(hv.x, wv.x, o[j]); o[j] = fmaf(hv.y, wv.y, o[j]); o[j] = fmaf(hv.z, wv.z, o[j]); o[j] = fmaf(hv.w, wv.w, o[j]);
+                }
+            }
+            bool vnan = false;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float r = tanhf(o[j]);
+                vnan |= (r != r);
+                hd.vfull[(size_t)b * KH_VALUE_WIDTH + lane + 64 * j] = r;
+            }
+            if (vnan) atomicOr(&hd.flags[1], 1);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        T128_STAMP(NL + 1, 1);
+        return;
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // drain the ring (tail re-fetches) before exit
 
@@ -1373,36 +1614,6 @@ __global__ __launch_bounds__(384) __attribute__((amdgpu_waves_per_eu(1, 2))) voi
 // (fp32 logits written, then read by the softmax) per 1 024 boards for 6.6 MFLOP per board.  The convolutions walk
 // the reduction in conv_mfma_kernel's order (logits bit-identical); the softmax sums in another order than
 // softmax4672_kernel, and is used at every batch size of a configuration, so batch splits still agree bit for bit.
-struct Head4Args {
-    const unsigned short* x;      // T [B][64][Ci], Ci = NP * 128
-    const unsigned short* w;      // policyconv chunks (Ci / 32 of 8 KB) then policyconv2 chunks (4), pack_layer_wide128 order
-    const float* shift1;          // [128] folded pbatchnorm shift
-    const float* bias2;           // [128] policyconv2 bias, planes >= 73 zero
-    float* policy;                // [B][4672]
-    float* logits;                // nullable [B][4672]
-    int* flags;                   // [0]: a NaN in some policy row (nn.cpp:176-177); [1]: in the value tensor (nn.cpp:179-180)
-    int B;
-    // value head (nn.cpp:83-88), nullable as a whole (vw == nullptr: the separate kernels run it)
-    const float* vw;              // [Ci] valueconv weight * vbatchnorm scale
-    float vshift;
-    const float* fcw;             // [256][64] valuefc.weight
-    const float* fcb;             // [256]
-    float* vfull;                 // [B][256]
-};
-
-__device__ __forceinline__ float wave_max_f(float v)
-{
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
-    return v;
-}
-__device__ __forceinline__ float wave_sum_f(float v)
-{
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-    return v;
-}
-
 template <typename T, int NP>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void policy_head4_kernel(Head4Args a)
 {
@@ -1508,12 +1719,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             // valueconv (C -> 1) on the staged board: lane (pixel, h) takes channels 64 h .. 64 h + 63 of this pass
             const float* vw = a.vw + pass * Ci + 64 * h;
 #pragma unroll
-            for (int hp = 0; hp < 2; ++hp) {
-                const char* row = smem + LDS_IMG + wave * board_bytes + (32 * hp + lp) * stride + h * 128;
+            for (int c8 = 0; c8 < 8; ++c8) {
+                const float4 w0 = *reinterpret_cast<const float4*>(vw + c8 * 8), w1 = *reinterpret_cast<const float4*>(vw + c8 * 8 + 4);
 #pragma unroll
-                for (int c8 = 0; c8 < 8; ++c8) {
+                for (int hp = 0; hp < 2; ++hp) {
+                    const char* row = smem + LDS_IMG + wave * board_bytes + (32 * hp + lp) * stride + h * 128;
                     const u32x4 u = *reinterpret_cast<const u32x4*>(row + c8 * 16);
-                    const float4 w0 = *reinterpret_cast<const float4*>(vw + c8 * 8), w1 = *reinterpret_cast<const float4*>(vw + c8 * 8 + 4);
                     float s = vsum[hp];
                     s = fmaf(from_bits<T>((unsigned short)(u.x & 0xffff)), w0.x, s); s = fmaf(from_bits<T>((unsigned short)(u.x >> 16)), w0.y, s);
                     s = fmaf(from_bits<T>((unsigned short)(u.y & 0xffff)), w0.z, s); s = fmaf(from_bits<T>((unsigned short)(u.y >> 16)), w0.w, s);
@@ -1559,10 +1770,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int ch = (i8 >> 1) * 32 + 8 * (r >> 2) + 4 * h + (r & 3);
-            if (ch < KH_POLICY_PLANES) sum += expf(acc[i8][r] - m);
+            if (ch < KH_POLICY_PLANES) sum += HEAD_EXP(acc[i8][r] - m);
         }
     sum = wave_sum_f(sum);
-    const float ls = logf(sum);
+    const float ls = HEAD_LOG(sum);
     const bool row_nan = __any(nan);                        // any NaN logit poisons the whole row in the reference
     // The lane layout (4 consecutive planes of one pixel per lane, pixels 292 bytes apart) makes a direct store 64
     // scattered 4-byte writes per instruction.  The row goes through LDS instead (ring and images are dead: one barrier
@@ -1581,7 +1792,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                     const int ch = ms * 32 + 8 * (r >> 2) + 4 * h + (r & 3);
                     if (ch < KH_POLICY_PLANES) {
                         const float v = acc[ms * 2 + hp][r];
-                        rowbuf[(32 * hp + lp) * KH_POLICY_PLANES + ch] = probs ? (row_nan ? NAN : expf((v - m) - ls)) : v;
+                        rowbuf[(32 * hp + lp) * KH_POLICY_PLANES + ch] = probs ? (row_nan ? NAN : HEAD_EXP((v - m) - ls)) : v;
                     }
                 }
         // (same wave wrote it: its LDS operations are ordered)
@@ -1608,19 +1819,25 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             if (h == 0) v64[32 * hp + lp] = relu_keep_nan(tot + a.vshift);
         }
         // (same wave wrote it: its LDS operations are ordered)
-        float o[4] = { a.fcb[lane * 4], a.fcb[lane * 4 + 1], a.fcb[lane * 4 + 2], a.fcb[lane * 4 + 3] };
+        // (the same sums as tower128_kernel's fused heads: lane l takes outputs l, l + 64, l + 128, l + 192 out of fc4)
+        float o[4] = { a.fcb[lane], a.fcb[lane + 64], a.fcb[lane + 128], a.fcb[lane + 192] };
 #pragma unroll 4
         for (int k4 = 0; k4 < 16; ++k4) {
             const float4 hv = *reinterpret_cast<const float4*>(v64 + k4 * 4);
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                const float4 wv = *reinterpret_cast<const float4*>(a.fcw + (size_t)(lane * 4 + j) * 64 + k4 * 4);
+                const float4 wv = *reinterpret_cast<const float4*>(a.fc4 + ((size_t)k4 * KH_VALUE_WIDTH + lane + 64 * j) * 4);
                 o[j] = fmaf(hv.x, wv.x, o[j]); o[j] = fmaf(hv.y, wv.y, o[j]); o[j] = fmaf(hv.z, wv.z, o[j]); o[j] = fmaf(hv.w, wv.w, o[j]);
             }
         }
-        float4 r = make_float4(tanhf(o[0]), tanhf(o[1]), tanhf(o[2]), tanhf(o[3]));
-        *reinterpret_cast<float4*>(a.vfull + (size_t)b * KH_VALUE_WIDTH + lane * 4) = r;
-        if (r.x != r.x || r.y != r.y || r.z != r.z || r.w != r.w) atomicOr(&a.flags[1], 1);
+        bool vnan = false;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float r = tanhf(o[j]);
+            vnan |= (r != r);
+            a.vfull[(size_t)b * KH_VALUE_WIDTH + lane + 64 * j] = r;
+        }
+        if (vnan) atomicOr(&a.flags[1], 1);
     }
 }
 
@@ -2169,15 +2386,26 @@ template <typename T> static hipError_t run(const LayersArgs& L, hipStream_t s)
     if (fused && !fused256) {
         static std::atomic<bool> attr_done{ false };
         if (!attr_done.load(std::memory_order_acquire)) {
-            if ((e = hipFuncSetAttribute(reinterpret_cast<const void*>(&tower128_kernel<T>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)) != hipSuccess) return e;
+            if ((e = hipFuncSetAttribute(reinterpret_cast<const void*>(&tower128_kernel<T, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)) != hipSuccess) return e;
+            if ((e = hipFuncSetAttribute(reinterpret_cast<const void*>(&tower128_kernel<T, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)) != hipSuccess) return e;
             attr_done.store(true, std::memory_order_release);
         }
         Tower128Args t8;
         t8.planes = direct ? L.in : nullptr; t8.F = L.F; t8.magic = (unsigned)((0x100000000ull + L.F - 1) / L.F);
         t8.in = L.act_in; t8.w = layer4(0); t8.shift = shift(0); t8.out = x; t8.B = L.B; t8.R = L.R;
-        hipLaunchKernelGGL((tower128_kernel<T>), dim3((L.B + 3) / 4), dim3(256), 4 * CHUNKB + 4 * NPIX * (128 * 2 + 16), s, t8);
-        if ((e = hipGetLastError()) != hipSuccess) return e;
         li = 1 + 2 * (size_t)L.R;
+        // both heads inside the same launch (KAMI_T128_HEAD=0: policy_head4_kernel behind it, the A/B baseline)
+        static const bool head_in = !(getenv("KAMI_T128_HEAD") && atoi(getenv("KAMI_T128_HEAD")) == 0);
+        if (head_in && L.wh && L.CP == 128) {
+            Head4Args& hd = t8.hd;
+            hd.x = nullptr; hd.w = L.wh; hd.shift1 = shift(li); hd.bias2 = shift(li + 1); hd.policy = L.policy; hd.logits = L.want_logits ? L.logits : nullptr;
+            hd.flags = L.flags; hd.B = L.B;
+            hd.vw = L.vw; hd.vshift = L.vshift; hd.fcw = L.fcw; hd.fcb = L.fcb; hd.fc4 = L.fc4; hd.vfull = L.vfull;
+            hipLaunchKernelGGL((tower128_kernel<T, true>), dim3((L.B + 3) / 4), dim3(256), 4 * CHUNKB + 4 * NPIX * (128 * 2 + 16), s, t8);
+            return hipGetLastError();
+        }
+        hipLaunchKernelGGL((tower128_kernel<T, false>), dim3((L.B + 3) / 4), dim3(256), 4 * CHUNKB + 4 * NPIX * (128 * 2 + 16), s, t8);
+        if ((e = hipGetLastError()) != hipSuccess) return e;
     }
     // stem                                                                  nn.cpp:62-65
     if (!fused && !fused256) {
@@ -2198,7 +2426,7 @@ template <typename T> static hipError_t run(const LayersArgs& L, hipStream_t s)
         Head4Args hd;
         hd.x = x; hd.w = L.wh; hd.shift1 = shift(li); hd.bias2 = shift(li + 1); hd.policy = L.policy; hd.logits = L.want_logits ? L.logits : nullptr;
         hd.flags = L.flags; hd.B = L.B;
-        hd.vw = L.vw; hd.vshift = L.vshift; hd.fcw = L.fcw; hd.fcb = L.fcb; hd.vfull = L.vfull;
+        hd.vw = L.vw; hd.vshift = L.vshift; hd.fcw = L.fcw; hd.fcb = L.fcb; hd.fc4 = L.fc4; hd.vfull = L.vfull;
         li += 2;
         const int lds = 4 * CHUNKB + 4 * 64 * (128 * 2 + 16) + 4 * 64 * 4;
         static std::atomic<bool> attr_done{ false };

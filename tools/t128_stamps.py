@@ -15,6 +15,7 @@ lib.kh_memcpy_h2d(nn.handle, d_in, x.ctypes.data_as(C.c_void_p), x.nbytes)
 ms = C.c_float(); assert lib.kh_time_infer_device(nn.handle, d_in, B, d_p, d_v, 50, C.byref(ms)) == 0
 st = np.zeros((256, 64, 4), np.uint64)
 assert raw.kh_debug_t128_stamps(st.ctypes.data_as(C.c_void_p), st.size) == 0
+full = st.astype(np.int64)
 st = st[:, :1 + 2 * R].astype(np.int64)
 loop = np.median(st[:, :, 1] - st[:, :, 0], axis=0); bnd = np.median(st[:, :, 2] - st[:, :, 1], axis=0)
 gap = np.median(st[:, 1:, 0] - st[:, :-1, 2], axis=0)
@@ -23,3 +24,11 @@ print(f"boundary {bnd.astype(int).tolist()}")
 print(f"  of which ReLU / skip / round / image writes {np.median(st[:, :, 3] - st[:, :, 1], axis=0).astype(int).tolist()}")
 print(f"  of which next layer's shifts {np.median(st[:, :, 2] - st[:, :, 3], axis=0).astype(int).tolist()}")
 print(f"kernel span per workgroup (first loop start -> last boundary end): {int(np.median(st[:, -1, 2] - st[:, 0, 0]))} clocks; sum loops {int(loop.sum())} boundaries {int(bnd.sum())}")
+
+NLh = 1 + 2 * R
+hs = full[:, NLh], full[:, NLh + 1]
+if np.median(hs[0][:, 0]) > 0:
+    t0 = full[:, NLh - 1, 2]                                   # end of the last boundary
+    names = (("heads start", hs[0][:, 0]), ("policy conv 1 done", hs[0][:, 1]), ("policy conv 2 done", hs[0][:, 2]), ("softmax sums done", hs[0][:, 3]),
+             ("rows through LDS, stores issued", hs[1][:, 0]), ("value FC done, stores drained", hs[1][:, 1]))
+    print("heads inside the launch (clocks since the last boundary's end, median over workgroups): " + "; ".join(f"{n} {int(np.median(v - t0))}" for n, v in names))
