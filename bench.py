@@ -182,7 +182,7 @@ def variant_legs(torch, lib, NN, W, L, device, prewarm):
     out = []
     specs = [("f32", 119, 64, 6, 512, "exact fp32 on v_mfma_f32_32x32x2_f32 (the reference's own precision)"),
              ("f16", 119, 64, 6, 512, "f16 operands, fp32 accumulate"),
-             ("bf16", 119, 128, 10, 1024, "configs[2]: tower128_kernel (the 3x3 stack in one launch) + policy_head4_kernel (layers_mfma.hip)"),
+             ("bf16", 119, 128, 10, 1024, "configs[2]: tower128_kernel — the 3x3 stack and both heads in ONE launch (layers_mfma.hip)"),
              ("f16", 119, 256, 20, 256, "configs[4]'s net at its per-GPU batch (2 048 boards on 8 GPUs): tower2s_kernel (two workgroups per board pair, output channels split) + policy_head4_kernel"),
              ("f16", 119, 256, 20, 2048, "configs[4]'s net at its evaluation batch: tower2b_kernel + policy_head4_kernel")]
     for dtype, F, Cc, R, B, note in specs:
