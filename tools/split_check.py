@@ -1,5 +1,5 @@
-"""tower2s_kernel (two workgroups per board pair, output channels split, halves exchanged per layer) against the default
-path on the same weights and planes: each in a process of its own (KAMI_WIDE_VARIANT is read once), outputs compared,
+"""tower2s_kernel (two workgroups per board pair, output channels split, halves exchanged per layer) against tower2b_kernel
+on the same weights and planes: each in a process of its own (KAMI_WIDE_VARIANT is read once), outputs compared,
 forward time of both.   python tools/split_check.py [R] [B] [dtype]"""
 import os, subprocess, sys, tempfile
 import numpy as np
@@ -32,19 +32,16 @@ R = int(sys.argv[1]) if len(sys.argv) > 1 else 2
 B = int(sys.argv[2]) if len(sys.argv) > 2 else 256
 dtype = sys.argv[3] if len(sys.argv) > 3 else "f16"
 res = {}
-for v in ("0", "7"):
+for v in ("6", "7"):
     path = os.path.join(tempfile.gettempdir(), f"split_{v}.npz")
     env = dict(os.environ)
-    if v != "0":
-        env["KAMI_WIDE_VARIANT"] = v
-    else:
-        env.pop("KAMI_WIDE_VARIANT", None)
+    env["KAMI_WIDE_VARIANT"] = v             # 6: tower2b_kernel (slices summed 0,1,2,3), 7: tower2s_kernel
     r = subprocess.run([sys.executable, "-c", CHILD, str(R), str(B), dtype, path], env=env, capture_output=True, text=True, timeout=600)
     if r.returncode:
         print("variant", v, "failed:", r.stderr[-1500:]); sys.exit(1)
     res[v] = np.load(path)
-a, b = res["0"], res["7"]
-print(f"20x256-like: R={R} B={B} {dtype}: default {float(a['ms']):.3f} ms   split {float(b['ms']):.3f} ms per forward")
+a, b = res["6"], res["7"]
+print(f"20x256-like: R={R} B={B} {dtype}: tower2b_kernel {float(a['ms']):.3f} ms   tower2s_kernel {float(b['ms']):.3f} ms per forward")
 for k in ("lg", "p", "vf"):
     d = np.abs(a[k] - b[k])
     print(f"  {k}: max |diff| {d.max():.3e}  mean {d.mean():.3e}  (max |value| {np.abs(a[k]).max():.3e})  identical rows {int((d.reshape(len(d), -1).max(1) == 0).sum())}/{len(d)}")
