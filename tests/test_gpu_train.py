@@ -275,19 +275,22 @@ def test_train_epochs_compose_and_batches_are_distinct():
 
 
 @pytest.mark.gpu
-def test_selfplay_train_cycle_two_generations():
+@pytest.mark.parametrize("C,R,dtype,evals", [(32, 2, "bf16", 150000), (256, 3, "f16", 40000)])
+def test_selfplay_train_cycle_two_generations(C, R, dtype, evals):
     """Rows f1-f4 together on this stack (kami_amd/cycle.py): the pool plays on the engine, finished games
-    become replay records, kh_train turns them into the next generation, the pool keeps playing on it."""
+    become replay records, kh_train turns them into the next generation, the pool keeps playing on it.
+    Second case: BASELINE configs[4]'s width and precision (256 filters, fp16; three blocks instead of twenty to keep
+    the test short) — the wide-net kernels serve the search, the trainer runs its two-slice 256-channel convolutions."""
     from kami_amd import search as S, cycle
     from kami_amd.replay import ReplayBuffer
-    F, C, R = 30, 32, 2
-    nn = NN(8, 8, F, 4672, filters=C, residuals=R, dtype="bf16", value_mode=L.KH_VALUE_PER_SAMPLE0)
+    F = 30
+    nn = NN(8, 8, F, 4672, filters=C, residuals=R, dtype=dtype, value_mode=L.KH_VALUE_PER_SAMPLE0)
     nn.load_weights(W.random_weights(F, C, R, seed=21, peaky=3.0), 0)
     pool = S.Pool(nn, games=256, threads=4, nodes=16, seed=7)
     replay = ReplayBuffer(cycle.OBSIZE, cycle.PSIZE, 4096, seed=1)
     p0, _ = nn.infer(np.zeros((1, 8, 8, 30), np.float32))
     for gen in range(2):
-        out = cycle.generation(nn, pool, replay, play_evals=150000, play_seconds=60.0, epochs=2, batchsize=8, sample=256)
+        out = cycle.generation(nn, pool, replay, play_evals=evals, play_seconds=60.0, epochs=2, batchsize=8, sample=256)
         assert out["games_finished"] > 0 and out["records"] > 0
         assert out["generation_after"] == gen + 1
         assert np.isfinite([out["first_loss"], out["last_loss"]]).all() and out["last_loss"] < out["first_loss"]
